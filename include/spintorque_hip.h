@@ -1,0 +1,188 @@
+/*
+ * spintorque_hip.h -- C-ABI of libspintorque_hip.so: the MI355X (gfx950) implementation of the
+ * SpinTorque-v0 env.step() hot path, vectorised over N independent macrospin environments.
+ *
+ * The reference (danieleschmidt/spin-torque-rl-gym) is pure Python and has no FFI of its own; the
+ * seam this library replaces is Python duck-typing at two levels (SURVEY.md section 8b):
+ *   env level    : SpinTorqueEnv.reset/step            (spin_torque_gym/envs/spin_torque_env.py:250-407)
+ *   solver level : RobustLLGSSolver.solve / LLGSSolver.solve
+ *                                                       (utils/robust_solver.py:75-150, physics/llgs_solver.py:51-180)
+ * Each entry point below cites the reference code it stands in for.  INTEGRATION.md shows the ctypes
+ * stub a maintainer of the reference would add to bind it.
+ *
+ * Conventions
+ *   - plain C types only; every pointer marked [dev] is a device (HBM) pointer owned by the caller
+ *     (any allocator: hipMalloc, a PyTorch-ROCm tensor's data_ptr(), ...); [host] pointers are host memory.
+ *   - per-env arrays are structure-of-arrays: component-major, env index fastest (m is [3][N], obs is [12][N]),
+ *     so that lane i of a wavefront touches element i of each row (coalesced).
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *     nothing synchronises with the host except stg_create/stg_destroy/stg_set_params*/stg_get_state/stg_set_state.
+ *   - return value 0 = success, negative = error (STG_E_*); stg_last_error() returns a thread-local message.
+ *   - one context per GPU; a context is not thread-safe.  Contexts are independent (no global state).
+ *   - IEEE fp64 state and arithmetic (the reference's NumPy float64); observations are rounded to fp32 last,
+ *     as the reference does (spin_torque_env.py:520).
+ */
+#ifndef SPINTORQUE_HIP_H
+#define SPINTORQUE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STG_ABI_VERSION 1
+
+typedef struct stg_ctx stg_ctx;
+
+enum {
+    STG_OK = 0,
+    STG_E_INVALID = -1,   /* bad argument */
+    STG_E_HIP = -2,       /* a HIP runtime call failed */
+    STG_E_NOMEM = -3,
+    STG_E_STATE = -4      /* call order (e.g. step before set_params/reset) */
+};
+
+/* integrator: which reference solver's semantics a step/solve follows */
+enum {
+    STG_SOLVER_RK4 = 0,   /* SimpleLLGSSolver(method='rk4') behind RobustLLGSSolver -- what SpinTorqueEnv builds
+                             (spin_torque_env.py:93-102; simple_solver.py:278-295) */
+    STG_SOLVER_EULER = 1, /* SimpleLLGSSolver(method='euler') (simple_solver.py:263-276) */
+    STG_SOLVER_RK45 = 2   /* LLGSSolver: SciPy solve_ivp(method='RK45') (llgs_solver.py:130-139) */
+};
+
+enum { STG_DEV_STT = 0, STG_DEV_SOT = 1, STG_DEV_VCMA = 2 };
+
+/* per-lane status written by stg_step / stg_solve */
+enum {
+    STG_STATUS_OK = 0,
+    STG_STATUS_NOOP = 1,       /* solver reported success=False -> magnetisation left unchanged
+                                  (spin_torque_env.py:461-467; robust_solver.py:140-150) */
+    STG_STATUS_RESET = 2,      /* success, but >= 1 sub-step took the non-finite -> [0,0,1] branch
+                                  (simple_solver.py:213-216) */
+    STG_STATUS_INACTIVE = 3    /* env was already terminated/truncated and autoreset is off: not stepped */
+};
+
+#define STG_MAX_TARGETS 8
+#define STG_MAX_CLASSES 64
+
+/* SpinTorqueEnv.__init__ keyword arguments + solver constructor arguments
+ * (spin_torque_env.py:36-53,93-102; llgs_solver.py:24-31; simple_solver.py:24-31) */
+typedef struct {
+    int32_t solver;                 /* STG_SOLVER_* */
+    int32_t thermal;                /* include_thermal_fluctuations */
+    double temperature;             /* K */
+    double gamma;                   /* 2.21e5 m/(A s) */
+    double max_step;                /* 1e-12 s */
+    double rtol, atol;              /* RK45: 1e-6, 1e-9 */
+    int32_t max_steps;              /* 100 */
+    int32_t n_targets;              /* len(target_states), <= STG_MAX_TARGETS */
+    double max_current;             /* 2e6 A/m^2 */
+    double max_duration;            /* 5e-9 s */
+    double success_threshold;       /* 0.9 */
+    double energy_penalty_weight;   /* 0.1 */
+    double targets[STG_MAX_TARGETS][3]; /* target_states, unit vectors (default +z, -z) */
+    uint64_t seed;                  /* key of the in-kernel Philox4x32-10 (thermal field, device-side resets) */
+    int64_t max_attempts;           /* RK45 attempt budget per solve; exceeded -> STG_STATUS_NOOP.  The reference has
+                                       no such guard (its stiff cases simply never return, SURVEY.md headline 3). */
+    int32_t skip_done;              /* 1: lanes whose episode already ended are not integrated (wavefront-level
+                                       early-out) and report STG_STATUS_INACTIVE; 0: reference behaviour (step anyway) */
+    int32_t reserved;
+} stg_config;
+
+/* one reference-style device_params dict, flattened with the defaults the reference's .get() calls use
+ * (simple_solver.py:126-131; llgs_solver.py:79-82,192-205; spin_torque_env.py:476,502; devices/*.py) */
+typedef struct {
+    double damping;                 /* 'damping' */
+    double ms;                      /* 'saturation_magnetization' */
+    double ku;                      /* 'uniaxial_anisotropy' */
+    double volume;                  /* 'volume' */
+    double polarization;            /* 'polarization' */
+    double easy_axis[3];            /* 'easy_axis', raw */
+    double demag[3];                /* 'demag_factors' (LLGSSolver), default 0,0,1 */
+    double a_ex;                    /* 'exchange_constant' (LLGSSolver), default 20e-12 */
+    double area;                    /* 'area', default 1e-14 */
+    double r_p, r_ap;               /* 'resistance_parallel', 'resistance_antiparallel' */
+    double ref_m[3];                /* 'reference_magnetization', raw */
+    double r_series;                /* SOT: 0.1*(rho_hm/t_hm)/(area*1e-12) (sot_mram.py:218-223); else 0 */
+    int32_t dev_type;               /* STG_DEV_* : selects the compute_resistance form */
+    int32_t params_valid;           /* outcome of validate_parameters(params,'stt_mram') (utils/validation.py:176-234),
+                                       evaluated by the host mirror; 0 -> every solve falls back (no-op) */
+} stg_device_params;
+
+/* ---- lifecycle -------------------------------------------------------------------------------------- */
+
+/* Allocates the SoA state for n_envs environments on GPU `device_id`.
+ * env_id0 = global index of this context's first env (multi-GPU shards: rank r owns [env_id0, env_id0+n_envs)),
+ * used only as the Philox counter so that results do not depend on the partition. */
+int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, const stg_config* cfg);
+void stg_destroy(stg_ctx* ctx);
+const char* stg_last_error(void);
+int stg_abi_version(void);
+
+/* ---- device parameter surface (spin_torque_gym.devices; DeviceFactory.create_device, device_factory.py:49-77) --- */
+
+/* n_classes parameter sets (<= STG_MAX_CLASSES) [host]; cls [dev] uint8[N] selects the set of each env
+ * (NULL: every env uses table[0]).  The derived per-class constants are staged in LDS by the kernels. */
+int stg_set_params(stg_ctx* ctx, const stg_device_params* table, int32_t n_classes, const uint8_t* cls);
+
+/* ---- env level ---------------------------------------------------------------------------------------- */
+
+/* SpinTorqueEnv.reset (spin_torque_env.py:250-308) for the envs with mask[i] != 0 (mask NULL: all).
+ * init_m / target [dev] double[3][N]: options['initial_state'] / options['target_state'] (normalised by the kernel as
+ * device.validate_magnetization does); NULL: drawn on the device (normal(0,1,3) normalised; uniform choice among
+ * cfg.targets) from Philox(seed, env_id, episode).  obs_out [dev] float[12][N] may be NULL. */
+int stg_reset(stg_ctx* ctx, const uint8_t* mask, const double* init_m, const double* target,
+              uint64_t seed, float* obs_out, void* stream);
+
+/* SpinTorqueEnv.step (spin_torque_env.py:310-407) for all N envs.
+ * actions [dev]: [2][N] (row 0 current density A/m^2, row 1 pulse duration s), float32 (act_f64 = 0) or float64.
+ * obs float[12][N]; reward float[N]; reward_f64 double[N] or NULL; terminated/truncated/status uint8[N]
+ * (status may be NULL). */
+int stg_step(stg_ctx* ctx, const void* actions, int32_t act_f64, float* obs, float* reward, double* reward_f64,
+             uint8_t* terminated, uint8_t* truncated, uint8_t* status, void* stream);
+
+/* K consecutive env steps in one launch (state stays in registers between steps).
+ * actions [K][2][N]; outputs as stg_step with a leading [K] dimension; out_every = 1 writes every step's outputs,
+ * 0 only the last step's (leading dimension 1).  autoreset != 0: an env whose episode ended at step k is reset on the
+ * device (as stg_reset with NULL init_m/target) before step k+1. */
+int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64, int32_t out_every, int32_t autoreset,
+                  float* obs, float* reward, double* reward_f64, uint8_t* terminated, uint8_t* truncated,
+                  uint8_t* status, void* stream);
+
+/* state access for parity checks and checkpoint/resume; all pointers [dev], any may be NULL.
+ * m, target: double[3][N]; total_energy: double[N]; step_count: int32[N]; rng_step: uint32[N]; done: uint8[N] */
+int stg_get_state(stg_ctx* ctx, double* m, double* target, double* total_energy, int32_t* step_count,
+                  uint32_t* rng_step, uint8_t* done, void* stream);
+int stg_set_state(stg_ctx* ctx, const double* m, const double* target, const double* total_energy,
+                  const int32_t* step_count, const uint32_t* rng_step, const uint8_t* done, void* stream);
+
+/* ---- solver level ------------------------------------------------------------------------------------- */
+
+/* RobustLLGSSolver.solve / LLGSSolver.solve over (0, T[i]) with current_func(t) = J[i] if t <= T[i] else 0 and zero
+ * applied field, as SpinTorqueEnv._simulate_dynamics calls it (spin_torque_env.py:442-459), for N independent
+ * problems.  m0 double[3][N]; J, T double[N]; m_final double[3][N] (last trajectory row; m0 when success = 0);
+ * n_points int32[N] (RK4/Euler: sub-steps n; RK45: accepted points excluding t0); success uint8[N].
+ * env_step: Philox counter word (thermal on only).  Uses the context's config and parameter table/classes. */
+int stg_solve(stg_ctx* ctx, const double* m0, const double* J, const double* T, uint32_t env_step,
+              double* m_final, int32_t* n_points, uint8_t* success, void* stream);
+
+/* as stg_solve, additionally recording the trajectory: the first traj_cap rows of t [traj_cap][N],
+ * m [traj_cap][3][N] (normalised rows, llgs_solver.py:152-153), energy [traj_cap][N] (llgs_solver.py:239-262;
+ * RK45 only, may be NULL).  Row 0 is t0. */
+int stg_solve_traj(stg_ctx* ctx, const double* m0, const double* J, const double* T, uint32_t env_step,
+                   int32_t traj_cap, double* t, double* m, double* energy,
+                   double* m_final, int32_t* n_points, uint8_t* success, void* stream);
+
+/* ---- thermal field (physics/thermal_model.py:12-137; simple_solver.py:378-386; llgs_solver.py:85-90,111-113) ---- */
+
+/* Brown field strength of class `cls` for the context's solver kind and temperature ([host] out). */
+int stg_thermal_strength(stg_ctx* ctx, int32_t cls, double* out);
+/* Dumps the standard normals the kernels would draw for RHS calls call0..call0+n_calls-1 of env step `env_step`:
+ * z [dev] double[n_calls][3][N].  Diagnostic entry used by the distribution tests. */
+int stg_thermal_normals(stg_ctx* ctx, uint32_t env_step, uint32_t call0, int32_t n_calls, double* z, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPINTORQUE_HIP_H */

@@ -1,0 +1,421 @@
+// stg_physics.hpp -- device-side physics of the SpinTorque-v0 step path for gfx950 (CDNA4).
+//
+// One macrospin per lane: every function here is straight-line fp64 VALU work on registers, so a
+// 64-wide wavefront integrates 64 independent environments in lock step.  Divergence (per-lane trip
+// counts, accept/reject) is handled by EXEC masking of the enclosing loops; there is no cross-lane
+// traffic and no MFMA (the path is an elementwise 3-vector ODE, not a contraction).
+//
+// Reference semantics followed (paths relative to /root/reference/spin_torque_gym/):
+//   SimpleLLGSSolver RHS / RK4 / Euler / normalisation ... physics/simple_solver.py:137-168,208-229,263-388
+//   RobustLLGSSolver input/output gates ................. utils/robust_solver.py:152-205
+//   LLGSSolver RHS / energy ............................. physics/llgs_solver.py:92-126,182-262
+//   SciPy RK45 (Dormand-Prince 5(4)) controller ......... scipy/integrate/_ivp/rk.py, common.py (scipy 1.15.3)
+//   compute_resistance .................................. devices/stt_mram.py:78-94, sot_mram.py:196-228, vcma_mram.py:236-257
+//   action clamp, observation, reward, termination ...... utils/monitoring.py:288-348, envs/spin_torque_env.py:310-524
+//
+// Floating point: IEEE fp64, denormals on, no fast-math.  FMA contraction is allowed in the RHS
+// algebra (it only changes roundings at the 1e-16 level; parity bound is 1e-5, measured ~1e-12) but
+// NOT where the reference's branch decisions hang on an exact rounding: sub-step times
+// use __dmul_rn/__dadd_rn.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace stg {
+
+// ---- per-class derived constants (host-computed in fp64, staged in LDS by the kernels) ----------
+enum ClassConst : int {
+    // SimpleLLGSSolver
+    C_EX = 0, C_EY, C_EZ,      // easy_axis / |easy_axis|                      simple_solver.py:318
+    C_HK,                      // 2*k_u/(mu_0*ms)                              simple_solver.py:370
+    C_MS,                      // saturation magnetisation
+    C_ALPHA,                   // damping
+    C_GEFF,                    // gamma/(1+alpha^2)                            simple_solver.py:337
+    C_POL,                     // polarization
+    C_MSV,                     // ms*volume                                    simple_solver.py:330
+    C_HS_SIMPLE,               // Brown strength, kb = 1.38e-23                simple_solver.py:380-383
+    // LLGSSolver
+    C_RX, C_RY, C_RZ,          // raw easy axis (not normalised)               llgs_solver.py:194-196
+    C_DX, C_DY, C_DZ,          // -ms*demag_factors                            llgs_solver.py:200-201
+    C_HEX,                     // (2*a_ex/(mu_0*ms))*0.1 or 0                  llgs_solver.py:205-209
+    C_BETA, C_BETAP,           // P*gamma/(2*ms*V), 0.1*beta                   llgs_solver.py:229-230
+    C_GAMMA,
+    C_HS_LLGS,                 // Brown strength, k_b = 1.380649e-23           llgs_solver.py:87-90
+    C_KUV,                     // k_u*volume          (energy, llgs_solver.py:256)
+    C_EDEMAG,                  // 0.5*mu_0*ms^2*volume (energy, llgs_solver.py:260)
+    C_NX, C_NY, C_NZ,          // demag_factors
+    // env
+    C_AREA, C_RP, C_RAP, C_TMR,
+    C_REFX, C_REFY, C_REFZ,    // reference_magnetization / |.|
+    C_RSERIES,
+    C_DEVTYPE,                 // STG_DEV_* as double
+    C_VALID,                   // validate_parameters outcome as double (0/1)
+    C_COUNT
+};
+
+struct V3 {
+    double x, y, z;
+};
+
+__device__ __forceinline__ V3 cross(const V3& a, const V3& b) {
+    return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ double dot(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ bool finite3(const V3& a) { return isfinite(a.x) && isfinite(a.y) && isfinite(a.z); }
+
+// ---- counter-based RNG: Philox4x32-10 (Salmon et al., SC'11) ------------------------------------
+// key = seed, counter = (env_id_lo, env_id_hi, env_step, call_idx): any lane can produce its draw for
+// any RHS call without state, so results are independent of the partition of envs over GPUs.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// three standard normals: 24-bit uniforms in (0,1), fp32 Box-Muller on the transcendental unit
+// (v_log_f32 / v_sin_f32 / v_cos_f32 take log2 and revolutions natively).
+__device__ __forceinline__ V3 thermal_normals(uint64_t seed, uint64_t env_id, uint32_t env_step, uint32_t call_idx) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)env_id, (uint32_t)(env_id >> 32), env_step, call_idx, (uint32_t)seed,
+                  (uint32_t)(seed >> 32), r);
+    const float s = 1.0f / 16777216.0f;
+    const float u0 = ((float)(r[0] >> 8) + 0.5f) * s, u1 = ((float)(r[1] >> 8) + 0.5f) * s;
+    const float u2 = ((float)(r[2] >> 8) + 0.5f) * s, u3 = ((float)(r[3] >> 8) + 0.5f) * s;
+    const float m2ln2 = -1.3862943611198906f;   // -2 ln 2
+    const float ra = __builtin_sqrtf(m2ln2 * __builtin_amdgcn_logf(u0));
+    const float rb = __builtin_sqrtf(m2ln2 * __builtin_amdgcn_logf(u2));
+    return V3{(double)(ra * __builtin_amdgcn_cosf(u1)), (double)(ra * __builtin_amdgcn_sinf(u1)),
+              (double)(rb * __builtin_amdgcn_cosf(u3))};
+}
+
+// ---- per-lane constant sets ----------------------------------------------------------------------
+struct SimpleK {            // A1/A2 constants of this lane's device class
+    V3 e;
+    double hk, ms, alpha, geff, hs;
+};
+struct LlgsK {              // A6 constants
+    V3 r, d;
+    double hk, hex, alpha, gamma, hs;
+};
+
+// A1 + A2: SimpleLLGSSolver._compute_dmdt with h_applied = 0.  aJ = P*J/(ms*V) or 0 when the stage sees no current.
+template <bool THERMAL>
+__device__ __forceinline__ V3 simple_rhs(const V3& m, const SimpleK& k, double aJ, const V3& z) {
+    const double c = k.hk * dot(m, k.e);
+    V3 h{c * k.e.x, c * k.e.y, c * k.e.z - k.ms * m.z};
+    if (THERMAL) h = V3{h.x + k.hs * z.x, h.y + k.hs * z.y, h.z + k.hs * z.z};   // simple_solver.py:384
+    const V3 p = cross(m, h);                 // precession
+    const V3 q = cross(m, p);                 // m x (m x H)
+    const V3 t = cross(m, k.e);
+    const V3 u = cross(m, t);                 // m x (m x p), p = easy axis
+    return V3{-k.geff * (p.x + k.alpha * q.x) + aJ * u.x, -k.geff * (p.y + k.alpha * q.y) + aJ * u.y,
+              -k.geff * (p.z + k.alpha * q.z) + aJ * u.z};
+}
+
+// SimpleLLGSSolver._validate_magnetization (simple_solver.py:208-229).
+// returns 0 = normalised, 1 = reset to +z; sets zero_row when the quotient is the all-zero row m/inf.
+__device__ __forceinline__ int simple_validate(V3& m, bool& zero_row) {
+    zero_row = false;
+    if (!finite3(m)) { m = V3{0.0, 0.0, 1.0}; return 1; }
+    const double mag = sqrt(dot(m, m));
+    if (mag < 1e-12) { m = V3{0.0, 0.0, 1.0}; return 1; }
+    m = V3{m.x / mag, m.y / mag, m.z / mag};   // finite / inf = 0: finite, so kept
+    zero_row = isinf(mag);
+    return 0;
+}
+
+// validation.validate_magnetization as a predicate (utils/validation.py:46-51)
+__device__ __forceinline__ bool validation_rejects(const V3& m) {
+    return !finite3(m) || sqrt(dot(m, m)) < 1e-12;
+}
+
+struct SolveOut {
+    V3 m;            // final row (unchanged input when !ok)
+    int32_t n;       // RK4/Euler: sub-steps; RK45: accepted points excluding t0
+    int32_t resets;  // sub-steps that took the non-finite -> +z branch
+    bool ok;
+};
+
+struct RngKey {
+    uint64_t seed, env_id;
+    uint32_t env_step;
+};
+
+// Optional trajectory recorder (stg_solve_traj): rows are written with env index fastest.
+struct Recorder {
+    double* t;       // [cap][N]
+    double* m;       // [cap][3][N]
+    double* e;       // [cap][N] or nullptr
+    int64_t N, i;
+    int32_t cap;
+    __device__ __forceinline__ void put(int32_t row, double tt, const V3& mm, double ee) const {
+        if (row < cap) {
+            if (t) t[(int64_t)row * N + i] = tt;
+            if (m) {
+                double* b = m + (int64_t)row * 3 * N + i;
+                b[0] = mm.x; b[N] = mm.y; b[2 * N] = mm.z;
+            }
+            if (e) e[(int64_t)row * N + i] = ee;
+        }
+    }
+};
+
+// A3 + A4 + A5: RobustLLGSSolver.solve -> SimpleLLGSSolver.solve, METHOD 0 = rk4, 1 = euler.
+template <int METHOD, bool THERMAL, bool RECORD>
+__device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double T, const SimpleK& k, double pol,
+                                                 double msv, bool class_valid, double temperature, double max_step,
+                                                 const RngKey& rk, const Recorder& rec) {
+    SolveOut o{m0, 0, 0, false};
+    // robust_solver.py:152-190 (_validate_inputs); any failure ends in the fallback result (:140-150)
+    if (validation_rejects(m0) || !(T > 0.0) || !class_valid || !(temperature > 0.0)) return o;
+    V3 m = m0;
+    bool zr;
+    int resets = simple_validate(m, zr);                                   // simple_solver.py:119
+    // simple_solver.py:137-139, in exactly these roundings
+    double dt = fmin(max_step, __ddiv_rn(T, 100.0));
+    int n = (int)__ddiv_rn(T, dt);
+    n = n < 10 ? 10 : n;
+    dt = __ddiv_rn(T, (double)n);
+    o.n = n;
+    const double half_dt = 0.5 * dt;
+    const bool useJ = fabs(J) > 1e-12;                                     // simple_solver.py:326
+    const double aJ = useJ ? (pol * J) / msv : 0.0;                        // simple_solver.py:330
+    bool fail = false;
+    const V3 zero{0.0, 0.0, 0.0};
+    if (RECORD) rec.put(0, 0.0, m, 0.0);
+    for (int i = 0; i < n; ++i) {
+        // t_i = linspace(0, T, n+1)[i] = i*step; stage times t_i + dt/2, t_i + dt; the pulse is on while
+        // t <= T (spin_torque_env.py:442-443).  Only the last stages can land 1 ulp beyond T.
+        const double ti = __dmul_rn((double)i, dt);
+        const double a2 = (__dadd_rn(ti, __dmul_rn(dt, 0.5)) <= T) ? aJ : 0.0;
+        const double a4 = (__dadd_rn(ti, dt) <= T) ? aJ : 0.0;
+        V3 mn;
+        if (METHOD == 1) {
+            const V3 h0 = THERMAL ? thermal_normals(rk.seed, rk.env_id, rk.env_step, 4u * i) : zero;
+            const V3 f = simple_rhs<THERMAL>(m, k, aJ, h0);
+            mn = V3{m.x + dt * f.x, m.y + dt * f.y, m.z + dt * f.z};
+        } else {
+            V3 z0 = zero, z1 = zero, z2 = zero, z3 = zero;
+            if (THERMAL) {
+                z0 = thermal_normals(rk.seed, rk.env_id, rk.env_step, 4u * i);
+                z1 = thermal_normals(rk.seed, rk.env_id, rk.env_step, 4u * i + 1u);
+                z2 = thermal_normals(rk.seed, rk.env_id, rk.env_step, 4u * i + 2u);
+                z3 = thermal_normals(rk.seed, rk.env_id, rk.env_step, 4u * i + 3u);
+            }
+            const V3 f1 = simple_rhs<THERMAL>(m, k, aJ, z0);
+            const V3 y2{m.x + half_dt * f1.x, m.y + half_dt * f1.y, m.z + half_dt * f1.z};
+            const V3 f2 = simple_rhs<THERMAL>(y2, k, a2, z1);
+            const V3 y3{m.x + half_dt * f2.x, m.y + half_dt * f2.y, m.z + half_dt * f2.z};
+            const V3 f3 = simple_rhs<THERMAL>(y3, k, a2, z2);
+            const V3 y4{m.x + dt * f3.x, m.y + dt * f3.y, m.z + dt * f3.z};
+            const V3 f4 = simple_rhs<THERMAL>(y4, k, a4, z3);
+            // m + (k1 + 2 k2 + 2 k3 + k4)/6 with k = dt*f
+            const double w = dt / 6.0;
+            mn = V3{m.x + w * ((f1.x + 2.0 * f2.x) + (2.0 * f3.x + f4.x)),
+                    m.y + w * ((f1.y + 2.0 * f2.y) + (2.0 * f3.y + f4.y)),
+                    m.z + w * ((f1.z + 2.0 * f2.z) + (2.0 * f3.z + f4.z))};
+        }
+        resets += simple_validate(mn, zr);                                 // simple_solver.py:168
+        fail |= zr;                                                        // robust_solver.py:192-205
+        m = mn;
+        if (RECORD) rec.put(i + 1, (i + 1 == n) ? T : __dmul_rn((double)(i + 1), dt), m, 0.0);
+    }
+    o.resets = resets;
+    if (fail) return o;
+    o.m = m;
+    o.ok = true;
+    return o;
+}
+
+// A6: LLGSSolver.solve::llgs_rhs.  bJ = beta*J, bpJ = beta'*J (0 when |J| < 1e-12 or the pulse is over).
+template <bool THERMAL>
+__device__ __forceinline__ V3 llgs_rhs(const V3& y, const LlgsK& k, double bJ, double bpJ, const V3& z) {
+    const double nn = sqrt(dot(y, y));
+    V3 m{0.0, 0.0, 1.0};
+    if (nn > 1e-12) m = V3{y.x / nn, y.y / nn, y.z / nn};                  // llgs_solver.py:97-101
+    const double c = k.hk * dot(m, k.r);
+    V3 h{(c * k.r.x + k.d.x * m.x) + k.hex * m.x, (c * k.r.y + k.d.y * m.y) + k.hex * m.y,
+         (c * k.r.z + k.d.z * m.z) + k.hex * m.z};
+    if (THERMAL) h = V3{h.x + k.hs * z.x, h.y + k.hs * z.y, h.z + k.hs * z.z};            // llgs_solver.py:111-113
+    const V3 mxh = cross(m, h);
+    V3 dm{-k.gamma * mxh.x, -k.gamma * mxh.y, -k.gamma * mxh.z};
+    const V3 mxdm = cross(m, dm);
+    dm = V3{dm.x + k.alpha * mxdm.x, dm.y + k.alpha * mxdm.y, dm.z + k.alpha * mxdm.z};   // llgs_solver.py:123
+    // p_hat = z: m x z = (my, -mx, 0); m x (m x z) = (mx mz, my mz, -(mx^2 + my^2))        llgs_solver.py:226-235
+    const V3 mxp{m.y, -m.x, 0.0};
+    const V3 mxmxp = cross(m, mxp);
+    return V3{dm.x + (bJ * mxmxp.x + bpJ * mxp.x), dm.y + (bJ * mxmxp.y + bpJ * mxp.y),
+              dm.z + (bJ * mxmxp.z + bpJ * mxp.z)};
+}
+
+struct LlgsEnergyK {
+    double kuv, edemag;
+    V3 r, nfac;
+};
+// llgs_solver.py:239-262 with h_applied = 0
+__device__ __forceinline__ double llgs_energy(const V3& m, const LlgsEnergyK& k) {
+    const double ct = dot(m, k.r);
+    return -k.kuv * (ct * ct) + k.edemag * (k.nfac.x * (m.x * m.x) + k.nfac.y * (m.y * m.y) + k.nfac.z * (m.z * m.z));
+}
+
+__device__ __forceinline__ double rms3(const V3& a) { return sqrt(dot(a, a)) / 1.7320508075688772; }   // common.py:63-65
+
+// A7 (+A8 when RECORD): scipy solve_ivp(RK45) as LLGSSolver.solve drives it.
+template <bool THERMAL, bool RECORD>
+__device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T, const LlgsK& k, double beta,
+                                               double betap, double rtol, double atol, double max_step,
+                                               int64_t max_attempts, const RngKey& rk, const Recorder& rec,
+                                               const LlgsEnergyK& ek) {
+    // Dormand-Prince tableau (rk.py:380-391)
+    constexpr double A21 = 1.0 / 5;
+    constexpr double A31 = 3.0 / 40, A32 = 9.0 / 40;
+    constexpr double A41 = 44.0 / 45, A42 = -56.0 / 15, A43 = 32.0 / 9;
+    constexpr double A51 = 19372.0 / 6561, A52 = -25360.0 / 2187, A53 = 64448.0 / 6561, A54 = -212.0 / 729;
+    constexpr double A61 = 9017.0 / 3168, A62 = -355.0 / 33, A63 = 46732.0 / 5247, A64 = 49.0 / 176, A65 = -5103.0 / 18656;
+    constexpr double B1 = 35.0 / 384, B3 = 500.0 / 1113, B4 = 125.0 / 192, B5 = -2187.0 / 6784, B6 = 11.0 / 84;
+    constexpr double E1 = -71.0 / 57600, E3 = 71.0 / 16695, E4 = -71.0 / 1920, E5 = 17253.0 / 339200, E6 = -22.0 / 525, E7 = 1.0 / 40;
+    constexpr double C2 = 1.0 / 5, C3 = 3.0 / 10, C4 = 4.0 / 5, C5 = 8.0 / 9;
+
+    SolveOut o{m0, 0, 0, false};
+    const bool useJ = !(fabs(J) < 1e-12);                                   // llgs_solver.py:222
+    const double bJ = useJ ? beta * J : 0.0, bpJ = useJ ? betap * J : 0.0;
+    uint32_t call = 0;
+    const V3 zero{0.0, 0.0, 0.0};
+    auto fun = [&](double t, const V3& y) -> V3 {
+        const bool on = t <= T;                                             // spin_torque_env.py:442-443
+        V3 z = zero;
+        if (THERMAL) z = thermal_normals(rk.seed, rk.env_id, rk.env_step, call);
+        ++call;
+        return llgs_rhs<THERMAL>(y, k, on ? bJ : 0.0, on ? bpJ : 0.0, z);
+    };
+    const double n0 = sqrt(dot(m0, m0));                                    // llgs_solver.py:76
+    V3 y{m0.x / n0, m0.y / n0, m0.z / n0};
+    double t = 0.0;
+    int32_t npts = 0;
+    auto emit = [&]() {
+        const double nn = sqrt(dot(y, y));                                  // llgs_solver.py:152-153
+        o.m = V3{y.x / nn, y.y / nn, y.z / nn};
+        if (RECORD) rec.put(npts, t, o.m, rec.e ? llgs_energy(o.m, ek) : 0.0);
+        ++npts;
+    };
+    emit();
+    V3 f = fun(t, y);
+    double h_abs;
+    {   // select_initial_step (common.py:68-134), order = error_estimator_order = 4
+        const V3 sc{atol + fabs(y.x) * rtol, atol + fabs(y.y) * rtol, atol + fabs(y.z) * rtol};
+        const double d0 = rms3(V3{y.x / sc.x, y.y / sc.y, y.z / sc.z});
+        const double d1 = rms3(V3{f.x / sc.x, f.y / sc.y, f.z / sc.z});
+        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        h0 = fmin(h0, T);
+        const V3 y1{y.x + h0 * f.x, y.y + h0 * f.y, y.z + h0 * f.z};
+        const V3 f1 = fun(__dadd_rn(t, h0), y1);
+        const double d2 = rms3(V3{(f1.x - f.x) / sc.x, (f1.y - f.y) / sc.y, (f1.z - f.z) / sc.z}) / h0;
+        const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : pow(0.01 / fmax(d1, d2), 0.2);
+        h_abs = fmin(fmin(100.0 * h0, h1), fmin(T, max_step));
+    }
+    bool ok = true;
+    int64_t attempts = 0;
+    while (t != T) {                                                        // base.py:175-206, ivp.py:654-661
+        const double ulp = __longlong_as_double(__double_as_longlong(t) + 1) - t;   // nextafter(t, inf) - t, t >= 0
+        const double min_step = 10.0 * ulp;                                 // rk.py:119
+        h_abs = h_abs > max_step ? max_step : (h_abs < min_step ? min_step : h_abs);
+        bool accepted = false, rejected = false;
+        V3 y_new = y, f_new = f;
+        double t_new = t;
+        while (!accepted) {
+            if (h_abs < min_step || attempts >= max_attempts) { ok = false; break; }
+            ++attempts;
+            t_new = __dadd_rn(t, h_abs);
+            if (t_new - T > 0.0) t_new = T;
+            const double h = __dsub_rn(t_new, t);
+            h_abs = fabs(h);
+            // rk_step (rk.py:14-70); stage times must not be contracted into FMAs (they gate the pulse)
+            const V3 k1 = f;
+            const V3 k2 = fun(__dadd_rn(t, __dmul_rn(C2, h)), V3{y.x + (k1.x * A21) * h, y.y + (k1.y * A21) * h, y.z + (k1.z * A21) * h});
+            const V3 k3 = fun(__dadd_rn(t, __dmul_rn(C3, h)),
+                              V3{y.x + (k1.x * A31 + k2.x * A32) * h, y.y + (k1.y * A31 + k2.y * A32) * h,
+                                 y.z + (k1.z * A31 + k2.z * A32) * h});
+            const V3 k4 = fun(__dadd_rn(t, __dmul_rn(C4, h)),
+                              V3{y.x + (k1.x * A41 + k2.x * A42 + k3.x * A43) * h, y.y + (k1.y * A41 + k2.y * A42 + k3.y * A43) * h,
+                                 y.z + (k1.z * A41 + k2.z * A42 + k3.z * A43) * h});
+            const V3 k5 = fun(__dadd_rn(t, __dmul_rn(C5, h)),
+                              V3{y.x + (k1.x * A51 + k2.x * A52 + k3.x * A53 + k4.x * A54) * h,
+                                 y.y + (k1.y * A51 + k2.y * A52 + k3.y * A53 + k4.y * A54) * h,
+                                 y.z + (k1.z * A51 + k2.z * A52 + k3.z * A53 + k4.z * A54) * h});
+            const V3 k6 = fun(__dadd_rn(t, h),
+                              V3{y.x + (k1.x * A61 + k2.x * A62 + k3.x * A63 + k4.x * A64 + k5.x * A65) * h,
+                                 y.y + (k1.y * A61 + k2.y * A62 + k3.y * A63 + k4.y * A64 + k5.y * A65) * h,
+                                 y.z + (k1.z * A61 + k2.z * A62 + k3.z * A63 + k4.z * A64 + k5.z * A65) * h});
+            y_new = V3{y.x + h * (k1.x * B1 + k3.x * B3 + k4.x * B4 + k5.x * B5 + k6.x * B6),
+                       y.y + h * (k1.y * B1 + k3.y * B3 + k4.y * B4 + k5.y * B5 + k6.y * B6),
+                       y.z + h * (k1.z * B1 + k3.z * B3 + k4.z * B4 + k5.z * B5 + k6.z * B6)};
+            f_new = fun(__dadd_rn(t, h), y_new);
+            const V3 ev{(k1.x * E1 + k3.x * E3 + k4.x * E4 + k5.x * E5 + k6.x * E6 + f_new.x * E7) * h,
+                        (k1.y * E1 + k3.y * E3 + k4.y * E4 + k5.y * E5 + k6.y * E6 + f_new.y * E7) * h,
+                        (k1.z * E1 + k3.z * E3 + k4.z * E4 + k5.z * E5 + k6.z * E6 + f_new.z * E7) * h};
+            const V3 sc{atol + fmax(fabs(y.x), fabs(y_new.x)) * rtol, atol + fmax(fabs(y.y), fabs(y_new.y)) * rtol,
+                        atol + fmax(fabs(y.z), fabs(y_new.z)) * rtol};
+            const double err = rms3(V3{ev.x / sc.x, ev.y / sc.y, ev.z / sc.z});
+            if (err < 1.0) {
+                double factor = (err == 0.0) ? 10.0 : fmin(10.0, 0.9 * pow(err, -0.2));
+                if (rejected) factor = fmin(1.0, factor);
+                h_abs *= factor;
+                accepted = true;
+            } else {
+                h_abs *= fmax(0.2, 0.9 * pow(err, -0.2));    // NaN error norms land here too, as in SciPy
+                rejected = true;
+            }
+        }
+        if (!ok) break;
+        t = t_new;
+        y = y_new;
+        f = f_new;
+        emit();
+    }
+    o.n = npts - 1;
+    o.ok = ok;
+    if (!ok) o.m = m0;
+    return o;
+}
+
+// A9: compute_resistance.  ref = normalised reference layer.
+__device__ __forceinline__ double resistance(const V3& m_in, int dev_type, double r_p, double r_ap, double tmr,
+                                             const V3& ref, double r_series) {
+    if (dev_type == 0) {
+        const double mn = sqrt(dot(m_in, m_in));               // base_device.py:112-116
+        const V3 m{m_in.x / mn, m_in.y / mn, m_in.z / mn};
+        const double r = r_p * (1.0 + tmr * (1.0 - dot(m, ref)) / 2.0);
+        return fmax(r, r_p * 0.5);
+    }
+    double r = r_p + (r_ap - r_p) * (1.0 - dot(m_in, ref)) / 2.0;
+    if (dev_type == 1) r = r + r_series;
+    return fmax(r, 1.0);
+}
+
+// A10: SafetyWrapper.validate_action (in the action's own dtype) + _parse_action (fp64)
+template <typename AT>
+__device__ __forceinline__ void parse_action(AT a0, AT a1, double max_current, double max_duration, double& J, double& T) {
+    const AT cmax = (AT)1e8, dmin = (AT)1e-12, dmax = (AT)1e-6;
+    if (!isnan(a0)) a0 = a0 < -cmax ? -cmax : (a0 > cmax ? cmax : a0);
+    if (!isnan(a1)) a1 = a1 < dmin ? dmin : (a1 > dmax ? dmax : a1);
+    if (isnan(a0) || isnan(a1) || isinf(a0) || isinf(a1)) { a0 = (AT)0; a1 = dmin; }
+    const double j = (double)a0, t = (double)a1;
+    J = j < -max_current ? -max_current : (j > max_current ? max_current : j);
+    T = t < 1e-12 ? 1e-12 : (t > max_duration ? max_duration : t);
+}
+
+__device__ __forceinline__ float obs_cast(double v) {
+    const float f = (float)v;
+    // SafetyWrapper.validate_observation: np.nan_to_num(nan=0, posinf=1e6, neginf=-1e6)
+    return isnan(f) ? 0.0f : (isinf(f) ? (f > 0 ? 1e6f : -1e6f) : f);
+}
+
+}  // namespace stg

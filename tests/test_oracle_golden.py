@@ -1,0 +1,202 @@
+"""Pins the CPU oracle (oracle/stg_oracle.c) against the golden vectors recorded from the imported
+Python reference (tests/golden/make_golden.py).  CPU only.
+
+Tolerances: the oracle follows the NumPy operation order without FMA, so RK4 results agree to a few
+ulp per sub-step (asserted <= 1e-12 absolute on unit vectors); SciPy's RK45 goes through BLAS dot
+products and libm pow whose last-bit behaviour the C code cannot replicate, asserted <= 1e-9
+(accept/reject sequences are additionally required to be identical: same point counts).
+"""
+import numpy as np
+import pytest
+
+from conftest import sot_default_params, stt_default_params, vcma_default_params
+
+
+def test_g1_simple_rk4_relax(golden, oracle_mod):
+    o = oracle_mod
+    g = golden("G1_simple_rk4_relax")
+    p = o.make_params(stt_default_params())
+    c = o.make_config("rk4")
+    worst = 0.0
+    for k in range(len(g["T"])):
+        r = o.simple_solve(g["m0"][g["m0_index"][k]], g["T"][k], p, c, 0.0)
+        assert r["success"] == bool(g["success"][k])
+        assert r["n_steps"] == g["n_steps"][k]
+        worst = max(worst, np.abs(r["m_final"] - g["m_final"][k]).max())
+    assert worst <= 1e-12, worst
+    # full trajectories
+    for tag, idx, T in (("traj0", 0, 1e-9), ("traj1", 29, float(np.float32(3.3e-10)))):
+        r = o.simple_solve(g["m0"][idx], T, p, c, 0.0, want_traj=True)
+        assert r["m"].shape == g[tag + "_m"].shape
+        assert np.abs(r["m"] - g[tag + "_m"]).max() <= 1e-12
+
+
+def test_g2_simple_rk4_stt(golden, oracle_mod):
+    o = oracle_mod
+    g = golden("G2_simple_rk4_stt")
+    c = o.make_config("rk4")
+    worst = 0.0
+    switched = 0
+    for k in range(len(g["T"])):
+        p = o.make_params(stt_default_params(volume=float(g["volume"][k])))
+        m0 = g["m0"][g["m0_index"][k]]
+        r = o.simple_solve(m0, g["T"][k], p, c, g["J"][k])
+        assert r["success"] == bool(g["success"][k])
+        assert r["n_steps"] == g["n_steps"][k]          # H5: truncation of T/dt
+        worst = max(worst, np.abs(r["m_final"] - g["m_final"][k]).max())
+        switched += int(m0[2] > 0.9 and g["m_final"][k][2] < -0.9)
+    assert worst <= 1e-11, worst
+    assert switched > 0                                  # the fixture does contain +z -> -z switching
+    p = o.make_params(stt_default_params(volume=float(g["traj_volume"])))
+    r = o.simple_solve(g["m0"][int(g["traj_m0_index"])], float(g["traj_T"]), p, c, float(g["traj_J"]), want_traj=True)
+    assert np.abs(r["m"] - g["traj_m"]).max() <= 1e-11
+
+
+def test_g3_simple_degenerate(golden, oracle_mod):
+    """Overflow semantics: success flag, first all-zero row, last row -- exactly."""
+    o = oracle_mod
+    g = golden("G3_simple_degenerate")
+    p = o.make_params(stt_default_params())
+    c = o.make_config("rk4")
+    n_fail = 0
+    for k in range(len(g["J"])):
+        r = o.simple_solve(g["m0"][g["m0_index"][k]], g["T"][k], p, c, g["J"][k])
+        assert r["success"] == bool(g["success"][k]), k
+        assert r["first_zero_row"] == g["first_zero_row"][k], k
+        if r["success"]:
+            assert np.abs(r["m_final"] - g["robust_m_last"][k]).max() <= 1e-12
+        else:
+            n_fail += 1
+    assert n_fail > 50
+
+
+@pytest.mark.parametrize("name,vols", [("G4_llgs_rk45_relax", {0: None}), ("G5_llgs_rk45_stt", {0: 9.7e-6, 1: 2e-6})])
+def test_g4_g5_llgs_rk45(golden, oracle_mod, name, vols):
+    o = oracle_mod
+    g = golden(name)
+    c = o.make_config("rk45")
+    for k, case in enumerate(g["cases"]):
+        m0, T, J, tag, succ = case[:3], case[3], case[4], int(case[5]), bool(case[6])
+        d = stt_default_params() if vols[tag] is None else stt_default_params(volume=vols[tag])
+        p = o.make_params(d)
+        r = o.llgs_solve(m0, T, p, c, J)
+        assert r["success"] == succ
+        assert r["n_points"] == len(g[f"t_{k}"]), (k, r["n_points"], len(g[f"t_{k}"]))
+        assert np.abs(r["t"] - g[f"t_{k}"]).max() <= 1e-9 * T
+        assert np.abs(r["m"] - g[f"m_{k}"]).max() <= 1e-9
+        e = g[f"energy_{k}"]
+        assert np.abs(r["energy"] - e).max() <= 1e-9 * np.abs(e).max()
+        tq = g[f"torques_{k}"]
+        assert np.abs(r["torques"] - tq).max() <= 1e-9 * max(np.abs(tq).max(), 1e-300)
+
+
+def _episode_params(tag):
+    if tag in ("default_relax", "default_noop", "temperature_zero_noop"):
+        return "stt_mram", stt_default_params()
+    if tag in ("stt_switch", "stt_bad_actions", "stt_custom_cfg"):
+        return "stt_mram", stt_default_params(volume=8.75e-11)
+    if tag == "sot_default_noop":
+        return "sot_mram", sot_default_params()
+    if tag == "sot_polarized":
+        return "sot_mram", sot_default_params(polarization=0.7, volume=8.75e-11)
+    if tag == "vcma_polarized_tilted":
+        return "vcma_mram", vcma_default_params(polarization=0.6, volume=5e-11, easy_axis=np.array([0.1, 0.0, 1.0]),
+                                                reference_magnetization=np.array([0.0, 0.2, 1.0]))
+    raise KeyError(tag)
+
+
+EPISODE_CFG = {
+    "stt_bad_actions": dict(max_steps=5),
+    "stt_custom_cfg": dict(max_current=1e6, max_duration=1e-9, success_threshold=0.5, energy_penalty_weight=0.3,
+                           temperature=350.0, max_steps=20),
+    "temperature_zero_noop": dict(temperature=0.0),
+}
+
+
+def test_g6_env_episode(golden, oracle_mod):
+    o = oracle_mod
+    g = golden("G6_env_episode")
+    for k, tag in enumerate(g["episode_tags"]):
+        tag = str(tag)
+        dev, d = _episode_params(tag)
+        p = o.make_params(d, dev)
+        c = o.make_config("rk4", thermal=False, **EPISODE_CFG.get(tag, {}))
+        s = o.EnvState()
+        m0 = g[f"ep{k}_m0"]
+        m0 = m0 / np.linalg.norm(m0)
+        tgt = g[f"ep{k}_target"]
+        tgt = tgt / np.linalg.norm(tgt)
+        s.m[:] = list(m0)
+        s.target[:] = list(tgt)
+        for j, a in enumerate(g[f"ep{k}_actions"]):
+            out = o.env_step(s, a, p, c)
+            ref_obs = g[f"ep{k}_obs"][j + 1]
+            assert np.allclose(np.array(out.obs[:]), ref_obs, rtol=2e-7, atol=1e-12), (tag, j, np.array(out.obs[:]), ref_obs)
+            ref_r = g[f"ep{k}_reward"][j]
+            assert abs(out.reward - ref_r) <= 1e-11 * max(1.0, abs(ref_r)), (tag, j, out.reward, ref_r)
+            assert bool(out.terminated) == bool(g[f"ep{k}_terminated"][j]), (tag, j)
+            assert bool(out.truncated) == bool(g[f"ep{k}_truncated"][j]), (tag, j)
+            assert (out.status != 1) == bool(g[f"ep{k}_success"][j]), (tag, j)
+            ref_e = g[f"ep{k}_energy"][j]
+            assert abs(out.energy - ref_e) <= 1e-13 * max(abs(ref_e), 1e-300), (tag, j)
+            assert np.abs(np.array(s.m[:]) - g[f"ep{k}_m"][j + 1]).max() <= 1e-11, (tag, j)
+
+
+def test_g7_resistance(golden, oracle_mod):
+    o = oracle_mod
+    g = golden("G7_resistance")
+    for dev, dflt in (("stt_mram", stt_default_params), ("sot_mram", sot_default_params), ("vcma_mram", vcma_default_params)):
+        p = o.make_params(dflt(), dev)
+        got = np.array([o.resistance(m, p) for m in g["m"]])
+        assert np.allclose(got, g[f"R_{dev}"], rtol=1e-14, atol=0)
+        p = o.make_params(dflt(reference_magnetization=np.array([0.0, 0.2, 1.0]), resistance_parallel=1234.5,
+                               resistance_antiparallel=3210.0), dev)
+        got = np.array([o.resistance(m, p) for m in g["m"]])
+        assert np.allclose(got, g[f"R_{dev}_tilted"], rtol=1e-14, atol=0)
+        p = o.make_params(dflt(), dev)
+        got = np.array([o.resistance(m * 1.7, p) for m in g["m"]])
+        assert np.allclose(got, g[f"R_{dev}_scaled"], rtol=1e-14, atol=0)
+    # the two numeric pins the reference's own tests hold (tests/unit/test_devices.py:84,89)
+    p = o.make_params(stt_default_params())
+    assert abs(o.resistance(np.array([0, 0, 1.0]), p) - 1e3) < 10
+    assert abs(o.resistance(np.array([0, 0, -1.0]), p) - 2e3) < 20
+
+
+def test_g8_thermal_strength_and_moments(golden, oracle_mod):
+    o = oracle_mod
+    g = golden("G8_thermal")
+    for alpha, ms, vol, T, s_llgs, s_simple in g["grid"]:
+        p = o.make_params(stt_default_params(damping=alpha, saturation_magnetization=ms, volume=vol))
+        assert np.isclose(o.thermal_strength(p, 2.21e5, T, 1), s_llgs, rtol=1e-15)
+        assert np.isclose(o.thermal_strength(p, 2.21e5, T, 0), s_simple, rtol=1e-15)
+    # the oracle's Philox/Box-Muller normals obey the moment bounds the reference's own thermal test uses
+    # (tests/test_comprehensive_suite.py:447-476: |mean| < 0.1 sigma, |std - sigma| < 0.2 sigma over 1000 draws)
+    z = np.array([o.thermal_normals(1234, e, 0, c) for e in range(50) for c in range(80)])
+    assert np.all(np.abs(z.mean(axis=0)) < 0.1)
+    assert np.all(np.abs(z.std(axis=0) - 1.0) < 0.2)
+    # tighter: 4000 draws -> standard error 0.016 / 0.011
+    assert np.all(np.abs(z.mean(axis=0)) < 0.06) and np.all(np.abs(z.std(axis=0) - 1.0) < 0.04)
+    # and the reference's own empirical field std (4000 draws) is consistent with sigma = strength
+    p = o.make_params(stt_default_params())
+    s = o.thermal_strength(p, 2.21e5, 300.0, 0)
+    assert np.all(np.abs(g["simple_field_std"] / s - 1.0) < 0.05)
+    assert np.isclose(o.thermal_strength(p, 2.21e5, 300.0, 1), float(g["default_strength_llgs"]), rtol=1e-15)
+
+
+def test_philox_known_answer(oracle_mod):
+    """Philox4x32-10 known-answer vectors from the Random123 distribution (kat_vectors)."""
+    import ctypes as C
+    L = oracle_mod.lib()
+    L.stgo_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
+    L.stgo_philox4x32_10.restype = None
+
+    def ph(ctr, key):
+        c = (C.c_uint32 * 4)(*ctr)
+        k = (C.c_uint32 * 2)(*key)
+        out = (C.c_uint32 * 4)()
+        L.stgo_philox4x32_10(c, k, out)
+        return [int(x) for x in out]
+    assert ph([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert ph([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert ph([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
