@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the SpinTorque-v0 step path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one env.step() of every environment of the batch: one launch of the fused step kernel per GPU (action
+clamp -> LLGS integration over the pulse -> energy -> observation -> reward -> termination), and for N > 1 the single
+all-gather of (obs, reward, terminated, truncated).  Inputs (states, the [K,2,N] action tensor) are resident in HBM
+before the timed region.  Weak scaling: --envs-per-gpu environments per GPU whatever N is.
+
+Headline workload (config.workload): BASELINE.json configs[2] / the north-star target -- 65 536 STT-MRAM environments
+per GPU, thermal field on at 300 K (in-kernel Philox), LLGSSolver semantics (SciPy RK45, rtol 1e-6, atol 1e-9,
+max_step 1 ps), random pulses J ~ U[-2e6, 2e6] A/m^2, duration ~ U[0.1, 1] ns (float32), `volume` rescaled to 9.7e-6 so
+that the Slonczewski term is well conditioned for RK45 (SURVEY.md headline 3: at the default volume any J != 0 makes
+the reference's solver diverge), device-side auto-reset of finished episodes.  `also` carries the other
+configurations (cfg2: 4096 envs T = 0 K; the env's own RK4 solver; cfg4: 262 144 mixed STT/SOT/VCMA envs).
+
+Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline` (the binding roof is fp64 VALU, not
+HBM -- SURVEY.md 8d -- both are reported) and `cpu_baseline` (the oracle, "port", on the host cores of this box).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "spin-torque-rl-gym_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+# algorithmic work per unit
+BYTES_PER_ENV_STEP = 160          # homogeneous params: 68 B read + 90 B written (+2 B rounding in the survey's figure)
+BYTES_PER_ENV_STEP_MIXED = 161    # + 1 B class index
+FLOPS_PER_RK4_SUBSTEP = 305
+FLOPS_PER_RK45_ATTEMPT = 745
+PEAK_FP64_VALU_TFLOPS = 78.6      # MI355X vector fp64 (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz)
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--envs-per-gpu", type=int, default=65536)
+    ap.add_argument("--solver", default="rk45", choices=["rk4", "rk45", "euler"])
+    ap.add_argument("--thermal", type=int, default=1)
+    ap.add_argument("--also", type=int, default=1, help="run the secondary configurations too (N=1 only)")
+    ap.add_argument("--cpu-baseline", type=int, default=1)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def stt_params(volume):
+    import spin_torque_gym_amd as stg
+    p = stg.DeviceFactory().get_default_parameters("stt_mram")
+    p["volume"] = volume
+    return p
+
+
+def make_actions(k, n, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    a = torch.empty((k, 2, n), dtype=torch.float32)
+    a[:, 0] = (torch.rand((k, n), generator=g) * 2 - 1) * 2e6
+    a[:, 1] = 1e-10 + torch.rand((k, n), generator=g) * 9e-10
+    return a.to(device)
+
+
+def volume_for(solver):
+    # regimes in which the current actually drives switching: RK4 8.75e-11, RK45 9.7e-6
+    return 9.7e-6 if solver == "rk45" else 8.75e-11
+
+
+def run_config(n_local, solver, thermal, steps, warmup, rank, world, device_index, mixed=False, seed=1234):
+    """Builds the env, runs warmup + timed steps, returns a dict of measurements (times are this rank's)."""
+    import spin_torque_gym_amd as stg
+    import torch.distributed as dist
+    kw = dict(include_thermal_fluctuations=bool(thermal), temperature=300.0, solver=solver, seed=seed, autoreset=True)
+    if mixed:
+        fac = stg.DeviceFactory()
+        sot = fac.get_default_parameters("sot_mram"); sot.update(polarization=0.7, volume=volume_for(solver))
+        vc = fac.get_default_parameters("vcma_mram"); vc.update(polarization=0.7, volume=volume_for(solver))
+        kw.update(device_type=["stt_mram", "sot_mram", "vcma_mram"], device_params=[stt_params(volume_for(solver)), sot, vc])
+        cls_global = (torch.arange(n_local * world) % 3).to(torch.uint8)
+    else:
+        kw.update(device_params=stt_params(volume_for(solver)))
+        cls_global = None
+    if world > 1:
+        from spin_torque_gym_amd.distributed import ShardedSpinTorqueVecEnv
+        env = ShardedSpinTorqueVecEnv(n_local * world, device_index=device_index, class_index=cls_global, **kw)
+        backend = env.local.backend
+    else:
+        env = stg.SpinTorqueVecEnv(n_local, device_index=device_index, class_index=cls_global, **kw)
+        backend = env.backend
+    dev = backend.device
+    acts = make_actions(warmup + steps, n_local, dev, seed + 17 * rank)
+    env.reset(seed=seed) if world == 1 else env.reset(seed=seed + rank, gather=False)
+
+    def one_step(k):
+        if world > 1:
+            _sharded_step(env, acts[k])
+        else:
+            backend.step(acts[k], autoreset=True)
+
+    for k in range(warmup):
+        one_step(k)
+    torch.cuda.synchronize(dev)
+    backend.counters(reset=True)
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        starts[k].record()
+        backend.step(acts[warmup + k], autoreset=True)          # the step kernel, on torch's current stream
+        ends[k].record()
+        if world > 1:
+            env._gather()                                        # the single collective of a step
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    kern_ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]
+    c = backend.counters()
+    env.close()
+    return dict(wall_s=t1 - t0, kernel_ms_avg=float(np.mean(kern_ms)), kernel_ms_min=float(np.min(kern_ms)),
+                env_steps=c["env_steps"], work_units=c["work_units"], noop_steps=c["noop_steps"])
+
+
+def _sharded_step(env, a):
+    env.local.backend.step(a, autoreset=True)
+    env._gather()
+
+
+def roofline(meas, n_local, steps, solver, mixed=False):
+    flops_per_unit = FLOPS_PER_RK45_ATTEMPT if solver == "rk45" else FLOPS_PER_RK4_SUBSTEP
+    launches = steps
+    t = meas["kernel_ms_avg"] * 1e-3
+    flops_per_launch = flops_per_unit * meas["work_units"] / launches
+    bytes_per_launch = (BYTES_PER_ENV_STEP_MIXED if mixed else BYTES_PER_ENV_STEP) * n_local
+    tf = flops_per_launch / t / 1e12
+    gbs = bytes_per_launch / t / 1e9
+    return {"bound": "valu_fp64", "achieved": round(tf, 4), "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / PEAK_FP64_VALU_TFLOPS, 5), "traffic": None,
+            "kernel": "stg_step_kernel", "kernel_ms_avg": round(meas["kernel_ms_avg"], 4),
+            "flops_per_work_unit": flops_per_unit,
+            "work_units_per_env_step": round(meas["work_units"] / max(meas["env_steps"], 1), 2),
+            "hbm": {"achieved": round(gbs, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 7),
+                    "bytes_per_env_step": BYTES_PER_ENV_STEP_MIXED if mixed else BYTES_PER_ENV_STEP}}
+
+
+def cpu_baseline(solver, thermal, seconds):
+    """The oracle (CPU restatement, "port") on this box's host cores, same workload distribution, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    from helpers import make_states, unit_rows
+    import spin_torque_gym_amd as stg
+    oracle.build()
+    n = 2048
+    rng = np.random.default_rng(3)
+    m0 = unit_rows(rng, n)
+    tgt = np.where(rng.integers(0, 2, (n, 1)) == 0, 1.0, -1.0) * np.array([[0.0, 0.0, 1.0]])
+    p = (oracle.Params * 1)(oracle.make_params(stt_params(volume_for(solver))))
+    c = oracle.make_config(solver=solver, thermal=bool(thermal), seed=1234)
+    threads = oracle.lib().stgo_max_threads()
+    done_steps, t_used, batches = 0, 0.0, 0
+    while t_used < seconds and batches < 64:
+        st = make_states(n, m0, tgt)
+        a = np.empty((n, 2), dtype=np.float32)
+        a[:, 0] = rng.uniform(-2e6, 2e6, n)
+        a[:, 1] = rng.uniform(1e-10, 1e-9, n)
+        t0 = time.perf_counter()
+        oracle.env_step_batch(st, a, p, None, c, env_id0=0, n_threads=threads)
+        t_used += time.perf_counter() - t0
+        done_steps += n
+        batches += 1
+    return {"value": round(done_steps / t_used, 1), "unit": "env-steps/s", "cores": int(threads), "kind": "port",
+            "sample": f"{batches} batches x {n} envs, one env.step each, same action distribution, solver={solver}, "
+                      f"thermal={int(bool(thermal))}, OpenMP over envs ({t_used:.1f} s of wall time)"}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_local = args.envs_per_gpu
+    meas = run_config(n_local, args.solver, args.thermal, args.steps, args.warmup, rank, world, local_rank)
+    wall = torch.tensor([meas["wall_s"]], dtype=torch.float64, device=torch.device("cuda", local_rank))
+    if world > 1:
+        dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+    wall_s = float(wall.item())
+    n_total = n_local * world
+    out = {
+        "metric": "env_steps_per_sec", "value": round(n_total * args.steps / wall_s, 1), "unit": "env-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall_s / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"cfg3: {n_local} STT-MRAM envs/GPU, thermal {'on 300K (in-kernel Philox)' if args.thermal else 'off'}, "
+                               f"solver={args.solver} ({'LLGSSolver SciPy-RK45 rtol1e-6 atol1e-9 max_step 1ps' if args.solver == 'rk45' else 'SimpleLLGSSolver fixed-step dt<=1ps'}), "
+                               f"full env.step, J~U[-2e6,2e6], pulse~U[0.1,1]ns f32, volume={volume_for(args.solver):g}, autoreset",
+                   "envs_per_gpu": n_local, "global_envs": n_total, "solver": args.solver, "thermal": bool(args.thermal),
+                   "parallelism": f"env-sharded x{world}, one all-gather of 54 B/env per step" if world > 1 else "single GPU"},
+        "roofline": roofline(meas, n_local, args.steps, args.solver),
+    }
+    if rank == 0 and world == 1 and args.also:
+        also = []
+        for name, n, solver, thermal, mixed in (
+                ("cfg2: 4096 STT envs, T=0K, rk45", 4096, "rk45", 0, False),
+                ("cfg2: 4096 STT envs, T=0K, rk4 (the env's own solver)", 4096, "rk4", 0, False),
+                ("cfg3: 65536 STT envs, thermal on, rk4", 65536, "rk4", 1, False),
+                ("cfg4: 262144 mixed STT/SOT/VCMA envs (class table in LDS), T=0K, rk4", 262144, "rk4", 0, True)):
+            if solver == args.solver and n == n_local and bool(thermal) == bool(args.thermal) and not mixed:
+                continue
+            m = run_config(n, solver, thermal, max(3, args.steps // 2), 1, 0, 1, local_rank, mixed=mixed)
+            st = max(3, args.steps // 2)
+            also.append({"workload": name, "value": round(n * st / m["wall_s"], 1), "unit": "env-steps/s",
+                         "ms_per_step": round(m["wall_s"] / st * 1e3, 4), "roofline": roofline(m, n, st, solver, mixed)})
+        out["also"] = also
+    if rank == 0 and world == 1 and args.cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.solver, args.thermal, args.cpu_seconds)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,7 +16,7 @@
  *   - per-env arrays are structure-of-arrays: component-major, env index fastest (m is [3][N], obs is [12][N]),
  *     so that lane i of a wavefront touches element i of each row (coalesced).
  *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*; NULL = default stream);
- *     nothing synchronises with the host except stg_create/stg_destroy/stg_set_params*/stg_get_state/stg_set_state.
+ *     nothing synchronises with the host except stg_create, stg_destroy and stg_set_params (stg_get_state / stg_set_state enqueue copies on `stream`).
  *   - return value 0 = success, negative = error (STG_E_*); stg_last_error() returns a thread-local message.
  *   - one context per GPU; a context is not thread-safe.  Contexts are independent (no global state).
  *   - IEEE fp64 state and arithmetic (the reference's NumPy float64); observations are rounded to fp32 last,
@@ -91,7 +91,7 @@ typedef struct {
 } stg_config;
 
 /* one reference-style device_params dict, flattened with the defaults the reference's .get() calls use
- * (simple_solver.py:126-131; llgs_solver.py:79-82,192-205; spin_torque_env.py:476,502; devices/*.py) */
+ * (simple_solver.py:126-131; llgs_solver.py:79-82,192-205; spin_torque_env.py:476,502; devices/ (all three device modules)) */
 typedef struct {
     double damping;                 /* 'damping' */
     double ms;                      /* 'saturation_magnetization' */
@@ -137,18 +137,19 @@ int stg_reset(stg_ctx* ctx, const uint8_t* mask, const double* init_m, const dou
 
 /* SpinTorqueEnv.step (spin_torque_env.py:310-407) for all N envs.
  * actions [dev]: [2][N] (row 0 current density A/m^2, row 1 pulse duration s), float32 (act_f64 = 0) or float64.
- * obs float[12][N]; reward float[N]; reward_f64 double[N] or NULL; terminated/truncated/status uint8[N]
- * (status may be NULL). */
+ * obs float[12][N]; reward float[N]; terminated/truncated uint8[N]; optional (may be NULL): reward_f64 double[N]
+ * (the reward before rounding to fp32), energy double[N] (info['energy_consumed'], spin_torque_env.py:474-480),
+ * status uint8[N] (STG_STATUS_*). */
 int stg_step(stg_ctx* ctx, const void* actions, int32_t act_f64, float* obs, float* reward, double* reward_f64,
-             uint8_t* terminated, uint8_t* truncated, uint8_t* status, void* stream);
+             double* energy, uint8_t* terminated, uint8_t* truncated, uint8_t* status, void* stream);
 
 /* K consecutive env steps in one launch (state stays in registers between steps).
  * actions [K][2][N]; outputs as stg_step with a leading [K] dimension; out_every = 1 writes every step's outputs,
  * 0 only the last step's (leading dimension 1).  autoreset != 0: an env whose episode ended at step k is reset on the
  * device (as stg_reset with NULL init_m/target) before step k+1. */
 int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64, int32_t out_every, int32_t autoreset,
-                  float* obs, float* reward, double* reward_f64, uint8_t* terminated, uint8_t* truncated,
-                  uint8_t* status, void* stream);
+                  float* obs, float* reward, double* reward_f64, double* energy, uint8_t* terminated,
+                  uint8_t* truncated, uint8_t* status, void* stream);
 
 /* state access for parity checks and checkpoint/resume; all pointers [dev], any may be NULL.
  * m, target: double[3][N]; total_energy: double[N]; step_count: int32[N]; rng_step: uint32[N]; done: uint8[N] */
@@ -156,6 +157,12 @@ int stg_get_state(stg_ctx* ctx, double* m, double* target, double* total_energy,
                   uint32_t* rng_step, uint8_t* done, void* stream);
 int stg_set_state(stg_ctx* ctx, const double* m, const double* target, const double* total_energy,
                   const int32_t* step_count, const uint32_t* rng_step, const uint8_t* done, void* stream);
+
+/* On-device metrics since creation / the last reset of the counters ([host] out[4]): env steps taken, integrator
+ * work units (RK4/Euler sub-steps, RK45 attempted steps), reserved, steps that ended as STG_STATUS_NOOP.
+ * Stands in for the host-side bookkeeping of EnvironmentMonitor / RobustLLGSSolver.get_statistics
+ * (utils/monitoring.py:30-268, utils/robust_solver.py:311-328).  Synchronises the device. */
+int stg_get_counters(stg_ctx* ctx, uint64_t* out, int32_t reset);
 
 /* ---- solver level ------------------------------------------------------------------------------------- */
 

@@ -1,0 +1,689 @@
+// spintorque_hip.hip -- kernels and C-ABI of libspintorque_hip.so (see include/spintorque_hip.h).
+//
+// Layout in HBM (all owned by the context, structure-of-arrays, env index fastest):
+//   mx,my,mz, tx,ty,tz, e_tot : f64[N]   step : i32[N]   rng : u32[N]   done : u8[N]       = 65 B/env
+//   class table                : f64[n_classes][C_COUNT]  (derived constants, <= 64 classes)
+//   cls                        : u8[N] (caller-owned) when n_classes > 1
+// One lane per env, 64-thread workgroups (one wavefront each) so that small batches still spread over
+// as many CUs as they have wavefronts; the hot loop lives entirely in registers.  With one device class the
+// constants are read through scalar loads (SGPRs); with several, the table is staged in LDS once per
+// workgroup and each lane reads its class row from there.
+#include "../../include/spintorque_hip.h"
+#include "stg_physics.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+using namespace stg;
+
+// ------------------------------------------------------------------------------------------------
+// kernel argument blocks
+// ------------------------------------------------------------------------------------------------
+struct StateView {
+    double *mx, *my, *mz, *tx, *ty, *tz, *etot;
+    int32_t* step;
+    uint32_t* rng;
+    uint8_t* done;
+};
+
+struct CfgView {
+    double temperature, max_step, rtol, atol, max_current, max_duration, thr, w_energy;
+    double targets[STG_MAX_TARGETS][3];
+    uint64_t seed;
+    int64_t max_attempts;
+    int32_t max_steps, n_targets, skip_done;
+};
+
+struct StepArgs {
+    StateView s;
+    CfgView c;
+    int64_t N, env_id0;
+    const double* ctab;
+    const uint8_t* cls;
+    int32_t ncls;
+    const void* actions;          // [K][2][N]
+    int32_t K, out_every, autoreset;
+    unsigned long long* counters; // [4]: env-steps, integrator sub-steps/attempts, RHS evaluations, no-op steps
+    float* obs;                   // [K or 1][12][N]
+    float* reward;                // [K or 1][N]
+    double *reward64, *energy;
+    uint8_t *term, *trunc, *status;
+};
+
+struct SolveArgs {
+    CfgView c;
+    int64_t N, env_id0;
+    const double* ctab;
+    const uint8_t* cls;
+    int32_t ncls;
+    const double *m0, *J, *T;
+    uint32_t env_step;
+    double* m_final;
+    int32_t* n_points;
+    uint8_t* success;
+    int32_t traj_cap;
+    double *traj_t, *traj_m, *traj_e;
+};
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+// Stages the class table in LDS (MULTI) and returns this lane's row.  With a single class the row is read
+// straight from the (wave-uniform) global pointer, which the compiler turns into scalar loads.
+template <bool MULTI>
+__device__ __forceinline__ const double* class_row(const double* ctab, const uint8_t* cls, int32_t ncls, int64_t i,
+                                                   bool in_range, double* lds) {
+    if (MULTI) {
+        for (int j = threadIdx.x; j < ncls * C_COUNT; j += blockDim.x) lds[j] = ctab[j];
+        __syncthreads();
+        const int c = in_range ? (int)cls[i] : 0;
+        return lds + (c < ncls ? c : 0) * C_COUNT;
+    }
+    return ctab;
+}
+
+__device__ __forceinline__ SimpleK load_simple(const double* r) {
+    return SimpleK{V3{r[C_EX], r[C_EY], r[C_EZ]}, r[C_HK], r[C_MS], r[C_ALPHA], r[C_GEFF], r[C_HS_SIMPLE]};
+}
+__device__ __forceinline__ LlgsK load_llgs(const double* r) {
+    return LlgsK{V3{r[C_RX], r[C_RY], r[C_RZ]}, V3{r[C_DX], r[C_DY], r[C_DZ]}, r[C_HK], r[C_HEX], r[C_ALPHA], r[C_GAMMA],
+                 r[C_HS_LLGS]};
+}
+__device__ __forceinline__ LlgsEnergyK load_energy(const double* r) {
+    return LlgsEnergyK{r[C_KUV], r[C_EDEMAG], V3{r[C_RX], r[C_RY], r[C_RZ]}, V3{r[C_NX], r[C_NY], r[C_NZ]}};
+}
+
+template <int SOLVER, bool THERMAL, bool RECORD>
+__device__ __forceinline__ SolveOut run_solver(const V3& m, double J, double T, const double* row, const CfgView& c,
+                                               const RngKey& rk, const Recorder& rec) {
+    if (SOLVER == STG_SOLVER_RK45) {
+        const LlgsK k = load_llgs(row);
+        LlgsEnergyK ek{};
+        if (RECORD) ek = load_energy(row);
+        return llgs_solve<THERMAL, RECORD>(m, J, T, k, row[C_BETA], row[C_BETAP], c.rtol, c.atol, c.max_step,
+                                           c.max_attempts, rk, rec, ek);
+    }
+    const SimpleK k = load_simple(row);
+    return simple_solve<SOLVER == STG_SOLVER_EULER ? 1 : 0, THERMAL, RECORD>(m, J, T, k, row[C_POL], row[C_MSV],
+                                                                           row[C_VALID] != 0.0, c.temperature,
+                                                                           c.max_step, rk, rec);
+}
+
+// SpinTorqueEnv.reset draws (spin_torque_env.py:286-299) from the device generator: normal(0,1,3) normalised and a
+// uniform choice among the target states.  Counter word 3 = 0xFFFFFFFF/0xFFFFFFFE keeps these draws apart from the
+// thermal field's (whose call index never gets there).
+__device__ __forceinline__ void device_reset_draw(uint64_t seed, uint64_t env_id, uint32_t rng_step, const CfgView& c,
+                                                  bool draw_m, bool draw_t, V3& m, V3& tgt) {
+    if (draw_m) {
+        V3 z = thermal_normals(seed ^ 0x9E3779B97F4A7C15ull, env_id, rng_step, 0xFFFFFFFFu);
+        const double n = sqrt(dot(z, z));
+        m = (n < 1e-12) ? V3{0.0, 0.0, 1.0} : V3{z.x / n, z.y / n, z.z / n};
+    }
+    if (draw_t) {
+        uint32_t r[4];
+        philox4x32_10((uint32_t)env_id, (uint32_t)(env_id >> 32), rng_step, 0xFFFFFFFEu,
+                      (uint32_t)(seed ^ 0x9E3779B97F4A7C15ull), (uint32_t)((seed ^ 0x9E3779B97F4A7C15ull) >> 32), r);
+        const int idx = (int)__umulhi(r[0], (uint32_t)c.n_targets);
+        tgt = V3{c.targets[idx][0], c.targets[idx][1], c.targets[idx][2]};
+    }
+}
+
+// A12: _get_observation (vector mode), written component-major.
+__device__ __forceinline__ void write_obs(float* obs, int64_t N, int64_t i, const V3& m, const V3& tgt, const double* row,
+                                          const CfgView& c, int32_t step, double etot, double J, double T) {
+    const V3 ref{row[C_REFX], row[C_REFY], row[C_REFZ]};
+    const double r = resistance(m, (int)row[C_DEVTYPE], row[C_RP], row[C_RAP], row[C_TMR], ref, row[C_RSERIES]);
+    obs[0 * N + i] = obs_cast(m.x);
+    obs[1 * N + i] = obs_cast(m.y);
+    obs[2 * N + i] = obs_cast(m.z);
+    obs[3 * N + i] = obs_cast(tgt.x);
+    obs[4 * N + i] = obs_cast(tgt.y);
+    obs[5 * N + i] = obs_cast(tgt.z);
+    obs[6 * N + i] = obs_cast(r / row[C_RP]);
+    obs[7 * N + i] = obs_cast(c.temperature / 300.0);
+    obs[8 * N + i] = obs_cast((double)(c.max_steps - step) / (double)c.max_steps);
+    obs[9 * N + i] = obs_cast(etot / 1e-12);
+    obs[10 * N + i] = obs_cast(J / c.max_current);
+    obs[11 * N + i] = obs_cast(T / c.max_duration);
+}
+
+// Adds the sum of v over the executing lanes of the wavefront to *dst with one atomic.  The lane mask is
+// wave-uniform, so the loop is scalar code (v_readlane per executing lane); it runs once per kernel.
+__device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned long long v) {
+    const unsigned long long active = __ballot(1);
+    const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    unsigned long long sum = 0;
+    for (unsigned long long rem = active; rem; rem &= rem - 1) {
+        const int l = __builtin_ctzll(rem);
+        sum += ((unsigned long long)__builtin_amdgcn_readlane(hi, l) << 32) | __builtin_amdgcn_readlane(lo, l);
+    }
+    if ((int)__lane_id() == __builtin_ctzll(active) && sum) atomicAdd(dst, sum);
+}
+
+// ------------------------------------------------------------------------------------------------
+// env.step kernel (A10-A14 around the solver), K fused steps per launch
+// ------------------------------------------------------------------------------------------------
+template <int SOLVER, bool THERMAL, bool MULTI, typename AT>
+__global__ void __launch_bounds__(64) stg_step_kernel(const StepArgs a) {
+    __shared__ double s_tab[MULTI ? STG_MAX_CLASSES * C_COUNT : 1];
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool in_range = i < a.N;
+    const double* row = class_row<MULTI>(a.ctab, a.cls, a.ncls, i, in_range, s_tab);
+    if (!in_range) return;
+    const int64_t N = a.N;
+    const uint64_t env_id = (uint64_t)(a.env_id0 + i);
+
+    V3 m{a.s.mx[i], a.s.my[i], a.s.mz[i]};
+    V3 tgt{a.s.tx[i], a.s.ty[i], a.s.tz[i]};
+    double etot = a.s.etot[i];
+    int32_t step = a.s.step[i];
+    uint32_t rng = a.s.rng[i];
+    bool done = a.s.done[i] != 0;
+    const AT* act = (const AT*)a.actions;
+    const Recorder norec{};
+    unsigned long long c_steps = 0, c_sub = 0, c_noop = 0;
+
+    for (int k = 0; k < a.K; ++k) {
+        if (a.autoreset && done) {
+            device_reset_draw(a.c.seed, env_id, rng, a.c, true, true, m, tgt);
+            etot = 0.0; step = 0; done = false;
+        }
+        double J, T;
+        parse_action<AT>(act[((int64_t)k * 2 + 0) * N + i], act[((int64_t)k * 2 + 1) * N + i], a.c.max_current,
+                         a.c.max_duration, J, T);
+        const bool last = (k == a.K - 1);
+        const int64_t ko = a.out_every ? k : 0;
+        const bool wr = a.out_every || last;
+        uint8_t st;
+        double reward, energy = 0.0;
+        bool is_success, truncated;
+        if (a.c.skip_done && done) {
+            // wavefront-level early-out: a wave whose lanes are all done skips the integrator entirely
+            st = STG_STATUS_INACTIVE; reward = 0.0;
+            is_success = dot(m, tgt) >= a.c.thr;
+            truncated = step >= a.c.max_steps;
+        } else {
+            const double prev_align = dot(m, tgt);                                   // spin_torque_env.py:338-339
+            const RngKey rk{a.c.seed, env_id, rng};
+            const SolveOut so = run_solver<SOLVER, THERMAL, false>(m, J, T, row, a.c, rk, norec);
+            if (fabs(J) > 1e-12) {                                                   // spin_torque_env.py:474-480
+                const V3 ref{row[C_REFX], row[C_REFY], row[C_REFZ]};
+                const double r = resistance(m, (int)row[C_DEVTYPE], row[C_RP], row[C_RAP], row[C_TMR], ref, row[C_RSERIES]);
+                const double v = J * r * row[C_AREA];
+                energy = (v * v) / r * T;
+            }
+            if (so.ok) {                                                             // spin_torque_env.py:461-467
+                const double nn = sqrt(dot(so.m, so.m));
+                m = V3{so.m.x / nn, so.m.y / nn, so.m.z / nn};
+            }
+            etot += energy;
+            step += 1;
+            rng += 1;
+            const double align = dot(m, tgt);                                        // spin_torque_env.py:350-353
+            is_success = align >= a.c.thr;
+            // default reward (spin_torque_env.py:184-207; rewards/composite_reward.py:65-126), H7 sign kept
+            reward = 10.0 * (is_success ? 10.0 : 0.0);
+            reward += (-a.c.w_energy) * (-energy / 1e-12);
+            reward += (align - prev_align);
+            if (isnan(reward) || isinf(reward)) reward = -1.0;                       // monitoring.py:332-348
+            reward = fmin(fmax(reward, -1e6), 1e6);
+            truncated = step >= a.c.max_steps;                                       // spin_torque_env.py:371-372
+            st = so.ok ? (so.resets > 0 ? STG_STATUS_RESET : STG_STATUS_OK) : STG_STATUS_NOOP;
+            c_steps += 1; c_sub += (unsigned long long)so.work; c_noop += so.ok ? 0 : 1;
+            done = is_success || truncated;
+        }
+        if (wr) {
+            write_obs(a.obs + ko * 12 * N, N, i, m, tgt, row, a.c, step, etot, J, T);
+            a.reward[ko * N + i] = (float)reward;
+            if (a.reward64) a.reward64[ko * N + i] = reward;
+            if (a.energy) a.energy[ko * N + i] = energy;
+            a.term[ko * N + i] = is_success ? 1 : 0;
+            a.trunc[ko * N + i] = truncated ? 1 : 0;
+            if (a.status) a.status[ko * N + i] = st;
+        }
+    }
+    a.s.mx[i] = m.x; a.s.my[i] = m.y; a.s.mz[i] = m.z;
+    a.s.tx[i] = tgt.x; a.s.ty[i] = tgt.y; a.s.tz[i] = tgt.z;
+    a.s.etot[i] = etot;
+    a.s.step[i] = step;
+    a.s.rng[i] = rng;
+    a.s.done[i] = done ? 1 : 0;
+    // on-device metrics (the reference's EnvironmentMonitor/solver stats are host-side bookkeeping): one atomic per
+    // counter per wavefront
+    wave_add(a.counters + 0, c_steps);
+    wave_add(a.counters + 1, c_sub);
+    wave_add(a.counters + 3, c_noop);
+}
+
+// ------------------------------------------------------------------------------------------------
+// solver-level seam
+// ------------------------------------------------------------------------------------------------
+template <int SOLVER, bool THERMAL, bool MULTI, bool RECORD>
+__global__ void __launch_bounds__(64) stg_solve_kernel(const SolveArgs a) {
+    __shared__ double s_tab[MULTI ? STG_MAX_CLASSES * C_COUNT : 1];
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool in_range = i < a.N;
+    const double* row = class_row<MULTI>(a.ctab, a.cls, a.ncls, i, in_range, s_tab);
+    if (!in_range) return;
+    const int64_t N = a.N;
+    const V3 m0{a.m0[i], a.m0[N + i], a.m0[2 * N + i]};
+    const RngKey rk{a.c.seed, (uint64_t)(a.env_id0 + i), a.env_step};
+    const Recorder rec{a.traj_t, a.traj_m, a.traj_e, N, i, a.traj_cap};
+    const SolveOut so = run_solver<SOLVER, THERMAL, RECORD>(m0, a.J[i], a.T[i], row, a.c, rk, rec);
+    a.m_final[i] = so.m.x; a.m_final[N + i] = so.m.y; a.m_final[2 * N + i] = so.m.z;
+    if (a.n_points) a.n_points[i] = so.n;
+    if (a.success) a.success[i] = so.ok ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// reset / state / diagnostics kernels
+// ------------------------------------------------------------------------------------------------
+struct ResetArgs {
+    StateView s;
+    CfgView c;
+    int64_t N, env_id0;
+    const double* ctab;
+    const uint8_t* cls;
+    int32_t ncls;
+    const uint8_t* mask;
+    const double *init_m, *target;
+    uint64_t seed;
+    float* obs;
+};
+
+__global__ void __launch_bounds__(64) stg_reset_kernel(const ResetArgs a) {
+    __shared__ double s_tab[STG_MAX_CLASSES * C_COUNT];
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool in_range = i < a.N;
+    const double* row = (a.ncls > 1) ? class_row<true>(a.ctab, a.cls, a.ncls, i, in_range, s_tab) : a.ctab;
+    if (!in_range) return;
+    const int64_t N = a.N;
+    if (a.mask && !a.mask[i]) {
+        if (a.obs) {   // unchanged env: report its current observation (last action unknown -> 0, as after reset)
+            const V3 m{a.s.mx[i], a.s.my[i], a.s.mz[i]}, t{a.s.tx[i], a.s.ty[i], a.s.tz[i]};
+            write_obs(a.obs, N, i, m, t, row, a.c, a.s.step[i], a.s.etot[i], 0.0, 0.0);
+        }
+        return;
+    }
+    V3 m{0, 0, 1}, t{0, 0, 1};
+    device_reset_draw(a.seed, (uint64_t)(a.env_id0 + i), a.s.rng[i], a.c, a.init_m == nullptr, a.target == nullptr, m, t);
+    if (a.init_m) {   // device.validate_magnetization (base_device.py:94-116): v / |v|
+        const V3 v{a.init_m[i], a.init_m[N + i], a.init_m[2 * N + i]};
+        const double n = sqrt(dot(v, v));
+        m = V3{v.x / n, v.y / n, v.z / n};
+    }
+    if (a.target) {
+        const V3 v{a.target[i], a.target[N + i], a.target[2 * N + i]};
+        const double n = sqrt(dot(v, v));
+        t = V3{v.x / n, v.y / n, v.z / n};
+    }
+    a.s.mx[i] = m.x; a.s.my[i] = m.y; a.s.mz[i] = m.z;
+    a.s.tx[i] = t.x; a.s.ty[i] = t.y; a.s.tz[i] = t.z;
+    a.s.etot[i] = 0.0;
+    a.s.step[i] = 0;
+    a.s.done[i] = 0;
+    if (a.obs) write_obs(a.obs, N, i, m, t, row, a.c, 0, 0.0, 0.0, 0.0);
+}
+
+__global__ void stg_normals_kernel(uint64_t seed, int64_t env_id0, int64_t N, uint32_t env_step, uint32_t call0,
+                                   int32_t n_calls, double* z) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    for (int c = 0; c < n_calls; ++c) {
+        const V3 v = thermal_normals(seed, (uint64_t)(env_id0 + i), env_step, call0 + (uint32_t)c);
+        double* b = z + (int64_t)c * 3 * N + i;
+        b[0] = v.x; b[N] = v.y; b[2 * N] = v.z;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(STG_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+    } while (0)
+
+struct stg_ctx {
+    int device;
+    int64_t N, env_id0;
+    stg_config cfg;
+    StateView s{};
+    void* slab = nullptr;
+    double* ctab = nullptr;           // device, [ncls][C_COUNT]
+    double h_ctab[STG_MAX_CLASSES][C_COUNT];
+    int32_t ncls = 0;
+    const uint8_t* cls = nullptr;     // caller-owned device pointer
+    unsigned long long* counters = nullptr;
+    bool have_params = false, have_state = false;
+};
+
+static CfgView cfg_view(const stg_config& c) {
+    CfgView v{};
+    v.temperature = c.temperature; v.max_step = c.max_step; v.rtol = c.rtol; v.atol = c.atol;
+    v.max_current = c.max_current; v.max_duration = c.max_duration; v.thr = c.success_threshold;
+    v.w_energy = c.energy_penalty_weight;
+    std::memcpy(v.targets, c.targets, sizeof(v.targets));
+    v.seed = c.seed; v.max_attempts = c.max_attempts; v.max_steps = c.max_steps; v.n_targets = c.n_targets;
+    v.skip_done = c.skip_done;
+    return v;
+}
+
+static int check_cfg(const stg_config* c) {
+    if (!c) return fail(STG_E_INVALID, "cfg is NULL");
+    if (c->solver < 0 || c->solver > 2) return fail(STG_E_INVALID, "cfg.solver must be STG_SOLVER_RK4/EULER/RK45");
+    if (c->n_targets < 1 || c->n_targets > STG_MAX_TARGETS) return fail(STG_E_INVALID, "cfg.n_targets out of range");
+    if (!(c->max_step > 0)) return fail(STG_E_INVALID, "cfg.max_step must be positive");
+    if (c->max_steps < 1) return fail(STG_E_INVALID, "cfg.max_steps must be >= 1");
+    if (!(c->max_current > 0) || !(c->max_duration > 0)) return fail(STG_E_INVALID, "cfg.max_current/max_duration must be positive");
+    if (c->solver == STG_SOLVER_RK45 && (!(c->rtol > 0) || !(c->atol >= 0))) return fail(STG_E_INVALID, "cfg.rtol/atol invalid");
+    if (c->solver == STG_SOLVER_RK45 && c->max_attempts < 1) return fail(STG_E_INVALID, "cfg.max_attempts must be >= 1");
+    return STG_OK;
+}
+
+extern "C" {
+
+const char* stg_last_error(void) { return g_err.c_str(); }
+int stg_abi_version(void) { return STG_ABI_VERSION; }
+
+int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, const stg_config* cfg) {
+    if (!out) return fail(STG_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (n_envs < 1) return fail(STG_E_INVALID, "n_envs must be >= 1");
+    if (env_id0 < 0) return fail(STG_E_INVALID, "env_id0 must be >= 0");
+    if (int rc = check_cfg(cfg)) return rc;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(STG_E_INVALID, "device_id out of range");
+    HIP_TRY(hipSetDevice(device_id));
+    stg_ctx* c = new (std::nothrow) stg_ctx();
+    if (!c) return fail(STG_E_NOMEM, "out of host memory");
+    c->device = device_id; c->N = n_envs; c->env_id0 = env_id0; c->cfg = *cfg;
+    // one slab: 7 f64 rows, then i32, u32, u8 rows (each row 256-B aligned)
+    auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+    const size_t N = (size_t)n_envs;
+    const size_t r8 = al(N * 8), r4 = al(N * 4), r1 = al(N);
+    const size_t total = 7 * r8 + 2 * r4 + r1 + al(sizeof(double) * STG_MAX_CLASSES * C_COUNT) + 256;
+    hipError_t e = hipMalloc(&c->slab, total);
+    if (e != hipSuccess) { delete c; return fail(STG_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    e = hipMemset(c->slab, 0, total);
+    if (e != hipSuccess) { (void)hipFree(c->slab); delete c; return fail(STG_E_HIP, std::string("hipMemset: ") + hipGetErrorString(e)); }
+    char* p = (char*)c->slab;
+    double** rows[7] = {&c->s.mx, &c->s.my, &c->s.mz, &c->s.tx, &c->s.ty, &c->s.tz, &c->s.etot};
+    for (auto r : rows) { *r = (double*)p; p += r8; }
+    c->s.step = (int32_t*)p; p += r4;
+    c->s.rng = (uint32_t*)p; p += r4;
+    c->s.done = (uint8_t*)p; p += r1;
+    c->ctab = (double*)p; p += al(sizeof(double) * STG_MAX_CLASSES * C_COUNT);
+    c->counters = (unsigned long long*)p;
+    *out = c;
+    return STG_OK;
+}
+
+void stg_destroy(stg_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->slab) (void)hipFree(ctx->slab);
+    delete ctx;
+}
+
+// Derived constants, in the reference's own operation order (each line cites the expression it evaluates).
+static void derive_class(const stg_device_params& p, const stg_config& cfg, double* r) {
+    const double mu0 = 4 * M_PI * 1e-7;                                          // simple_solver.py:60
+    const double en = std::sqrt((p.easy_axis[0] * p.easy_axis[0] + p.easy_axis[1] * p.easy_axis[1]) + p.easy_axis[2] * p.easy_axis[2]);
+    r[C_EX] = p.easy_axis[0] / en; r[C_EY] = p.easy_axis[1] / en; r[C_EZ] = p.easy_axis[2] / en;   // simple_solver.py:318
+    r[C_HK] = (2 * p.ku) / (mu0 * p.ms);                                         // simple_solver.py:370 == llgs_solver.py:196
+    r[C_MS] = p.ms;
+    r[C_ALPHA] = p.damping;
+    r[C_GEFF] = cfg.gamma / (1 + p.damping * p.damping);                         // simple_solver.py:337
+    r[C_POL] = p.polarization;
+    r[C_MSV] = p.ms * p.volume;                                                  // simple_solver.py:330
+    r[C_HS_SIMPLE] = std::sqrt(2 * p.damping * 1.38e-23 * cfg.temperature / (mu0 * p.ms * p.volume * cfg.gamma));   // :380-383
+    r[C_RX] = p.easy_axis[0]; r[C_RY] = p.easy_axis[1]; r[C_RZ] = p.easy_axis[2];
+    r[C_DX] = -p.ms * p.demag[0]; r[C_DY] = -p.ms * p.demag[1]; r[C_DZ] = -p.ms * p.demag[2];   // llgs_solver.py:201
+    r[C_HEX] = p.a_ex > 0 ? (2 * p.a_ex / (mu0 * p.ms)) * 0.1 : 0.0;             // llgs_solver.py:205-209
+    r[C_BETA] = p.polarization * cfg.gamma / (2 * p.ms * p.volume);              // llgs_solver.py:229
+    r[C_BETAP] = 0.1 * r[C_BETA];                                                // llgs_solver.py:230
+    r[C_GAMMA] = cfg.gamma;
+    r[C_HS_LLGS] = std::sqrt(2 * p.damping * 1.380649e-23 * cfg.temperature / (cfg.gamma * mu0 * p.ms * p.volume));  // llgs_solver.py:87-90
+    r[C_KUV] = p.ku * p.volume;                                                  // llgs_solver.py:256
+    r[C_EDEMAG] = 0.5 * mu0 * (p.ms * p.ms) * p.volume;                          // llgs_solver.py:260
+    r[C_NX] = p.demag[0]; r[C_NY] = p.demag[1]; r[C_NZ] = p.demag[2];
+    r[C_AREA] = p.area; r[C_RP] = p.r_p; r[C_RAP] = p.r_ap;
+    r[C_TMR] = (p.r_ap - p.r_p) / p.r_p;                                         // stt_mram.py:88
+    const double rn = std::sqrt((p.ref_m[0] * p.ref_m[0] + p.ref_m[1] * p.ref_m[1]) + p.ref_m[2] * p.ref_m[2]);
+    r[C_REFX] = p.ref_m[0] / rn; r[C_REFY] = p.ref_m[1] / rn; r[C_REFZ] = p.ref_m[2] / rn;
+    r[C_RSERIES] = p.r_series;
+    r[C_DEVTYPE] = (double)p.dev_type;
+    r[C_VALID] = p.params_valid ? 1.0 : 0.0;
+}
+
+int stg_set_params(stg_ctx* ctx, const stg_device_params* table, int32_t n_classes, const uint8_t* cls) {
+    if (!ctx || !table) return fail(STG_E_INVALID, "ctx/table is NULL");
+    if (n_classes < 1 || n_classes > STG_MAX_CLASSES) return fail(STG_E_INVALID, "n_classes must be in [1, STG_MAX_CLASSES]");
+    if (n_classes > 1 && !cls) return fail(STG_E_INVALID, "cls is required when n_classes > 1");
+    for (int k = 0; k < n_classes; ++k) {
+        const stg_device_params& p = table[k];
+        if (p.dev_type < 0 || p.dev_type > 2) return fail(STG_E_INVALID, "dev_type must be STG_DEV_STT/SOT/VCMA");
+        // BaseSpintronicDevice/STTMRAMDevice._validate_parameters raise on these at construction
+        // (devices/stt_mram.py:46-53); the host mirror raises before getting here.
+        if (!(p.volume > 0) || !(p.ms > 0)) return fail(STG_E_INVALID, "volume and saturation_magnetization must be positive");
+        derive_class(p, ctx->cfg, ctx->h_ctab[k]);
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpy(ctx->ctab, ctx->h_ctab, sizeof(double) * n_classes * C_COUNT, hipMemcpyHostToDevice));
+    ctx->ncls = n_classes;
+    ctx->cls = n_classes > 1 ? cls : nullptr;
+    ctx->have_params = true;
+    return STG_OK;
+}
+
+int stg_thermal_strength(stg_ctx* ctx, int32_t cls, double* out) {
+    if (!ctx || !out) return fail(STG_E_INVALID, "ctx/out is NULL");
+    if (!ctx->have_params) return fail(STG_E_STATE, "stg_set_params has not been called");
+    if (cls < 0 || cls >= ctx->ncls) return fail(STG_E_INVALID, "cls out of range");
+    *out = ctx->h_ctab[cls][ctx->cfg.solver == STG_SOLVER_RK45 ? C_HS_LLGS : C_HS_SIMPLE];
+    return STG_OK;
+}
+
+static inline dim3 grid_for(int64_t N) { return dim3((unsigned)((N + 63) / 64)); }
+
+int stg_reset(stg_ctx* ctx, const uint8_t* mask, const double* init_m, const double* target, uint64_t seed,
+              float* obs_out, void* stream) {
+    if (!ctx) return fail(STG_E_INVALID, "ctx is NULL");
+    if (!ctx->have_params) return fail(STG_E_STATE, "stg_set_params must be called before stg_reset");
+    HIP_TRY(hipSetDevice(ctx->device));
+    ResetArgs a{};
+    a.s = ctx->s; a.c = cfg_view(ctx->cfg); a.N = ctx->N; a.env_id0 = ctx->env_id0;
+    a.ctab = ctx->ctab; a.cls = ctx->cls; a.ncls = ctx->ncls;
+    a.mask = mask; a.init_m = init_m; a.target = target; a.seed = seed; a.obs = obs_out;
+    hipLaunchKernelGGL(stg_reset_kernel, grid_for(ctx->N), dim3(64), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    ctx->have_state = true;
+    return STG_OK;
+}
+
+extern "C++" {
+template <int SOLVER, bool THERMAL, bool MULTI>
+static void launch_step(const StepArgs& a, int act_f64, hipStream_t st) {
+    if (act_f64)
+        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, double>), grid_for(a.N), dim3(64), 0, st, a);
+    else
+        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, float>), grid_for(a.N), dim3(64), 0, st, a);
+}
+template <int SOLVER>
+static void dispatch_step(const StepArgs& a, bool thermal, bool multi, int act_f64, hipStream_t st) {
+    if (thermal) { if (multi) launch_step<SOLVER, true, true>(a, act_f64, st); else launch_step<SOLVER, true, false>(a, act_f64, st); }
+    else { if (multi) launch_step<SOLVER, false, true>(a, act_f64, st); else launch_step<SOLVER, false, false>(a, act_f64, st); }
+}
+}  // extern "C++"
+
+int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64, int32_t out_every, int32_t autoreset,
+                  float* obs, float* reward, double* reward_f64, double* energy, uint8_t* terminated,
+                  uint8_t* truncated, uint8_t* status, void* stream) {
+    if (!ctx) return fail(STG_E_INVALID, "ctx is NULL");
+    if (!ctx->have_params || !ctx->have_state) return fail(STG_E_STATE, "stg_set_params and stg_reset must precede stg_step");
+    if (K < 1) return fail(STG_E_INVALID, "K must be >= 1");
+    if (!actions || !obs || !reward || !terminated || !truncated) return fail(STG_E_INVALID, "actions/obs/reward/terminated/truncated must not be NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    StepArgs a{};
+    a.s = ctx->s; a.c = cfg_view(ctx->cfg); a.N = ctx->N; a.env_id0 = ctx->env_id0;
+    a.ctab = ctx->ctab; a.cls = ctx->cls; a.ncls = ctx->ncls;
+    a.counters = ctx->counters;
+    a.actions = actions; a.K = K; a.out_every = out_every ? 1 : 0; a.autoreset = autoreset ? 1 : 0;
+    a.obs = obs; a.reward = reward; a.reward64 = reward_f64; a.energy = energy; a.term = terminated; a.trunc = truncated; a.status = status;
+    // the Simple solver only draws a thermal field when temperature > 0 (simple_solver.py:321,378)
+    const bool thermal = ctx->cfg.thermal && ctx->cfg.temperature > 0;
+    const bool multi = ctx->ncls > 1;
+    hipStream_t st = (hipStream_t)stream;
+    switch (ctx->cfg.solver) {
+        case STG_SOLVER_RK4: dispatch_step<STG_SOLVER_RK4>(a, thermal, multi, act_f64, st); break;
+        case STG_SOLVER_EULER: dispatch_step<STG_SOLVER_EULER>(a, thermal, multi, act_f64, st); break;
+        default: dispatch_step<STG_SOLVER_RK45>(a, ctx->cfg.thermal != 0, multi, act_f64, st); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return STG_OK;
+}
+
+int stg_step(stg_ctx* ctx, const void* actions, int32_t act_f64, float* obs, float* reward, double* reward_f64,
+             double* energy, uint8_t* terminated, uint8_t* truncated, uint8_t* status, void* stream) {
+    return stg_step_many(ctx, 1, actions, act_f64, 1, 0, obs, reward, reward_f64, energy, terminated, truncated, status,
+                         stream);
+}
+
+extern "C++" {
+template <int SOLVER, bool RECORD>
+static void dispatch_solve(const SolveArgs& a, bool thermal, bool multi, hipStream_t st) {
+    const dim3 g = grid_for(a.N), b(64);
+    if (thermal) {
+        if (multi) hipLaunchKernelGGL((stg_solve_kernel<SOLVER, true, true, RECORD>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((stg_solve_kernel<SOLVER, true, false, RECORD>), g, b, 0, st, a);
+    } else {
+        if (multi) hipLaunchKernelGGL((stg_solve_kernel<SOLVER, false, true, RECORD>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((stg_solve_kernel<SOLVER, false, false, RECORD>), g, b, 0, st, a);
+    }
+}
+}  // extern "C++"
+
+static int solve_common(stg_ctx* ctx, const double* m0, const double* J, const double* T, uint32_t env_step,
+                        int32_t traj_cap, double* tt, double* tm, double* te, double* m_final, int32_t* n_points,
+                        uint8_t* success, void* stream, bool record) {
+    if (!ctx) return fail(STG_E_INVALID, "ctx is NULL");
+    if (!ctx->have_params) return fail(STG_E_STATE, "stg_set_params must precede stg_solve");
+    if (!m0 || !J || !T || !m_final) return fail(STG_E_INVALID, "m0/J/T/m_final must not be NULL");
+    if (record && traj_cap < 1) return fail(STG_E_INVALID, "traj_cap must be >= 1");
+    HIP_TRY(hipSetDevice(ctx->device));
+    SolveArgs a{};
+    a.c = cfg_view(ctx->cfg); a.N = ctx->N; a.env_id0 = ctx->env_id0;
+    a.ctab = ctx->ctab; a.cls = ctx->cls; a.ncls = ctx->ncls;
+    a.m0 = m0; a.J = J; a.T = T; a.env_step = env_step; a.m_final = m_final; a.n_points = n_points; a.success = success;
+    a.traj_cap = traj_cap; a.traj_t = tt; a.traj_m = tm; a.traj_e = te;
+    const bool multi = ctx->ncls > 1;
+    hipStream_t st = (hipStream_t)stream;
+    const bool th_simple = ctx->cfg.thermal && ctx->cfg.temperature > 0, th_llgs = ctx->cfg.thermal != 0;
+    switch (ctx->cfg.solver) {
+        case STG_SOLVER_RK4:
+            if (record) dispatch_solve<STG_SOLVER_RK4, true>(a, th_simple, multi, st); else dispatch_solve<STG_SOLVER_RK4, false>(a, th_simple, multi, st);
+            break;
+        case STG_SOLVER_EULER:
+            if (record) dispatch_solve<STG_SOLVER_EULER, true>(a, th_simple, multi, st); else dispatch_solve<STG_SOLVER_EULER, false>(a, th_simple, multi, st);
+            break;
+        default:
+            if (record) dispatch_solve<STG_SOLVER_RK45, true>(a, th_llgs, multi, st); else dispatch_solve<STG_SOLVER_RK45, false>(a, th_llgs, multi, st);
+            break;
+    }
+    HIP_TRY(hipGetLastError());
+    return STG_OK;
+}
+
+int stg_solve(stg_ctx* ctx, const double* m0, const double* J, const double* T, uint32_t env_step, double* m_final,
+              int32_t* n_points, uint8_t* success, void* stream) {
+    return solve_common(ctx, m0, J, T, env_step, 0, nullptr, nullptr, nullptr, m_final, n_points, success, stream, false);
+}
+
+int stg_solve_traj(stg_ctx* ctx, const double* m0, const double* J, const double* T, uint32_t env_step, int32_t traj_cap,
+                   double* t, double* m, double* energy, double* m_final, int32_t* n_points, uint8_t* success,
+                   void* stream) {
+    return solve_common(ctx, m0, J, T, env_step, traj_cap, t, m, energy, m_final, n_points, success, stream, true);
+}
+
+int stg_get_state(stg_ctx* ctx, double* m, double* target, double* total_energy, int32_t* step_count, uint32_t* rng_step,
+                  uint8_t* done, void* stream) {
+    if (!ctx) return fail(STG_E_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t N = (size_t)ctx->N;
+    if (m) {
+        HIP_TRY(hipMemcpyAsync(m, ctx->s.mx, N * 8, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(m + N, ctx->s.my, N * 8, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(m + 2 * N, ctx->s.mz, N * 8, hipMemcpyDeviceToDevice, st));
+    }
+    if (target) {
+        HIP_TRY(hipMemcpyAsync(target, ctx->s.tx, N * 8, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(target + N, ctx->s.ty, N * 8, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(target + 2 * N, ctx->s.tz, N * 8, hipMemcpyDeviceToDevice, st));
+    }
+    if (total_energy) HIP_TRY(hipMemcpyAsync(total_energy, ctx->s.etot, N * 8, hipMemcpyDeviceToDevice, st));
+    if (step_count) HIP_TRY(hipMemcpyAsync(step_count, ctx->s.step, N * 4, hipMemcpyDeviceToDevice, st));
+    if (rng_step) HIP_TRY(hipMemcpyAsync(rng_step, ctx->s.rng, N * 4, hipMemcpyDeviceToDevice, st));
+    if (done) HIP_TRY(hipMemcpyAsync(done, ctx->s.done, N, hipMemcpyDeviceToDevice, st));
+    return STG_OK;
+}
+
+int stg_set_state(stg_ctx* ctx, const double* m, const double* target, const double* total_energy,
+                  const int32_t* step_count, const uint32_t* rng_step, const uint8_t* done, void* stream) {
+    if (!ctx) return fail(STG_E_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t N = (size_t)ctx->N;
+    if (m) {
+        HIP_TRY(hipMemcpyAsync(ctx->s.mx, m, N * 8, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(ctx->s.my, m + N, N * 8, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(ctx->s.mz, m + 2 * N, N * 8, hipMemcpyDeviceToDevice, st));
+    }
+    if (target) {
+        HIP_TRY(hipMemcpyAsync(ctx->s.tx, target, N * 8, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(ctx->s.ty, target + N, N * 8, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(ctx->s.tz, target + 2 * N, N * 8, hipMemcpyDeviceToDevice, st));
+    }
+    if (total_energy) HIP_TRY(hipMemcpyAsync(ctx->s.etot, total_energy, N * 8, hipMemcpyDeviceToDevice, st));
+    if (step_count) HIP_TRY(hipMemcpyAsync(ctx->s.step, step_count, N * 4, hipMemcpyDeviceToDevice, st));
+    if (rng_step) HIP_TRY(hipMemcpyAsync(ctx->s.rng, rng_step, N * 4, hipMemcpyDeviceToDevice, st));
+    if (done) HIP_TRY(hipMemcpyAsync(ctx->s.done, done, N, hipMemcpyDeviceToDevice, st));
+    if (m && target) ctx->have_state = true;
+    return STG_OK;
+}
+
+int stg_get_counters(stg_ctx* ctx, uint64_t* out, int32_t reset) {
+    if (!ctx || !out) return fail(STG_E_INVALID, "ctx/out is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, ctx->counters, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(ctx->counters, 0, 4 * sizeof(uint64_t)));
+    return STG_OK;
+}
+
+int stg_thermal_normals(stg_ctx* ctx, uint32_t env_step, uint32_t call0, int32_t n_calls, double* z, void* stream) {
+    if (!ctx || !z) return fail(STG_E_INVALID, "ctx/z is NULL");
+    if (n_calls < 1) return fail(STG_E_INVALID, "n_calls must be >= 1");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(stg_normals_kernel, dim3((unsigned)((ctx->N + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       ctx->cfg.seed, ctx->env_id0, ctx->N, env_step, call0, n_calls, z);
+    HIP_TRY(hipGetLastError());
+    return STG_OK;
+}
+
+}  // extern "C"

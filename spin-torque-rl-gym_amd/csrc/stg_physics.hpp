@@ -141,6 +141,7 @@ struct SolveOut {
     V3 m;            // final row (unchanged input when !ok)
     int32_t n;       // RK4/Euler: sub-steps; RK45: accepted points excluding t0
     int32_t resets;  // sub-steps that took the non-finite -> +z branch
+    int64_t work;    // integrator work units: RK4/Euler sub-steps, RK45 attempted steps
     bool ok;
 };
 
@@ -173,7 +174,7 @@ template <int METHOD, bool THERMAL, bool RECORD>
 __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double T, const SimpleK& k, double pol,
                                                  double msv, bool class_valid, double temperature, double max_step,
                                                  const RngKey& rk, const Recorder& rec) {
-    SolveOut o{m0, 0, 0, false};
+    SolveOut o{m0, 0, 0, 0, false};
     // robust_solver.py:152-190 (_validate_inputs); any failure ends in the fallback result (:140-150)
     if (validation_rejects(m0) || !(T > 0.0) || !class_valid || !(temperature > 0.0)) return o;
     V3 m = m0;
@@ -185,6 +186,7 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
     n = n < 10 ? 10 : n;
     dt = __ddiv_rn(T, (double)n);
     o.n = n;
+    o.work = n;
     const double half_dt = 0.5 * dt;
     const bool useJ = fabs(J) > 1e-12;                                     // simple_solver.py:326
     const double aJ = useJ ? (pol * J) / msv : 0.0;                        // simple_solver.py:330
@@ -284,7 +286,7 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
     constexpr double E1 = -71.0 / 57600, E3 = 71.0 / 16695, E4 = -71.0 / 1920, E5 = 17253.0 / 339200, E6 = -22.0 / 525, E7 = 1.0 / 40;
     constexpr double C2 = 1.0 / 5, C3 = 3.0 / 10, C4 = 4.0 / 5, C5 = 8.0 / 9;
 
-    SolveOut o{m0, 0, 0, false};
+    SolveOut o{m0, 0, 0, 0, false};
     const bool useJ = !(fabs(J) < 1e-12);                                   // llgs_solver.py:222
     const double bJ = useJ ? beta * J : 0.0, bpJ = useJ ? betap * J : 0.0;
     uint32_t call = 0;
@@ -381,6 +383,7 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
         emit();
     }
     o.n = npts - 1;
+    o.work = attempts;
     o.ok = ok;
     if (!ok) o.m = m0;
     return o;

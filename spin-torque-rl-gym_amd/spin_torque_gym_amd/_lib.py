@@ -1,0 +1,90 @@
+"""ctypes binding of libspintorque_hip.so (include/spintorque_hip.h).
+
+The library is the product: there is no CPU fallback.  Loading fails loudly (ImportError/RuntimeError)
+when the shared object has not been built (run ``python __graft_entry__.py`` or
+``make -C spin-torque-rl-gym_amd/csrc``), and every compute entry point needs a visible MI355X.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspintorque_hip.so")
+
+STG_MAX_TARGETS = 8
+STG_MAX_CLASSES = 64
+SOLVERS = {"rk4": 0, "euler": 1, "rk45": 2}
+DEV_TYPES = {"stt_mram": 0, "sot_mram": 1, "vcma_mram": 2}
+STATUS_OK, STATUS_NOOP, STATUS_RESET, STATUS_INACTIVE = 0, 1, 2, 3
+
+
+class StgConfig(C.Structure):
+    _fields_ = [
+        ("solver", C.c_int32), ("thermal", C.c_int32), ("temperature", C.c_double), ("gamma", C.c_double),
+        ("max_step", C.c_double), ("rtol", C.c_double), ("atol", C.c_double), ("max_steps", C.c_int32),
+        ("n_targets", C.c_int32), ("max_current", C.c_double), ("max_duration", C.c_double),
+        ("success_threshold", C.c_double), ("energy_penalty_weight", C.c_double),
+        ("targets", (C.c_double * 3) * STG_MAX_TARGETS), ("seed", C.c_uint64), ("max_attempts", C.c_int64),
+        ("skip_done", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class StgDeviceParams(C.Structure):
+    _fields_ = [
+        ("damping", C.c_double), ("ms", C.c_double), ("ku", C.c_double), ("volume", C.c_double),
+        ("polarization", C.c_double), ("easy_axis", C.c_double * 3), ("demag", C.c_double * 3),
+        ("a_ex", C.c_double), ("area", C.c_double), ("r_p", C.c_double), ("r_ap", C.c_double),
+        ("ref_m", C.c_double * 3), ("r_series", C.c_double), ("dev_type", C.c_int32), ("params_valid", C.c_int32),
+    ]
+
+
+# every symbol include/spintorque_hip.h declares: (restype, argtypes)
+_VP = C.c_void_p
+SYMBOLS = {
+    "stg_create": (C.c_int, [C.POINTER(_VP), C.c_int, C.c_int64, C.c_int64, C.POINTER(StgConfig)]),
+    "stg_destroy": (None, [_VP]),
+    "stg_last_error": (C.c_char_p, []),
+    "stg_abi_version": (C.c_int, []),
+    "stg_set_params": (C.c_int, [_VP, C.POINTER(StgDeviceParams), C.c_int32, _VP]),
+    "stg_reset": (C.c_int, [_VP, _VP, _VP, _VP, C.c_uint64, _VP, _VP]),
+    "stg_step": (C.c_int, [_VP, _VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "stg_step_many": (C.c_int, [_VP, C.c_int32, _VP, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "stg_get_state": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "stg_set_state": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "stg_get_counters": (C.c_int, [_VP, C.POINTER(C.c_uint64), C.c_int32]),
+    "stg_solve": (C.c_int, [_VP, _VP, _VP, _VP, C.c_uint32, _VP, _VP, _VP, _VP]),
+    "stg_solve_traj": (C.c_int, [_VP, _VP, _VP, _VP, C.c_uint32, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "stg_thermal_strength": (C.c_int, [_VP, C.c_int32, C.POINTER(C.c_double)]),
+    "stg_thermal_normals": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_int32, _VP, _VP]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library and bind every declared symbol.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension has not been built.  Build it with "
+            f"`python __graft_entry__.py` (or `make -C spin-torque-rl-gym_amd/csrc`).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.stg_abi_version() != 1:
+        raise ImportError(f"ABI version mismatch: library reports {lib.stg_abi_version()}, binding expects 1")
+    _lib = lib
+    return lib
+
+
+class StgError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().stg_last_error()
+        raise StgError(f"libspintorque_hip error {rc}: {msg.decode() if msg else '?'}")

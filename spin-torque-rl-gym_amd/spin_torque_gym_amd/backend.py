@@ -1,0 +1,252 @@
+"""HipBackend: one `stg_ctx` on one MI355X, driven through the C-ABI.
+
+PyTorch-ROCm is used only as the device-memory container (tensors) and for the stream the kernels are
+enqueued on; every computation happens in libspintorque_hip.so.  There is no CPU implementation here:
+constructing a HipBackend without the built library or without a visible GPU raises.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+@dataclass
+class EnvConfig:
+    """SpinTorqueEnv.__init__ keyword arguments that reach the step path (spin_torque_env.py:36-53) plus the
+    solver constructor arguments (llgs_solver.py:24-31, simple_solver.py:24-31)."""
+    solver: str = "rk4"                       # 'rk4' | 'euler' (SimpleLLGSSolver) | 'rk45' (LLGSSolver)
+    include_thermal_fluctuations: bool = True
+    temperature: float = 300.0
+    gamma: float = 2.21e5
+    max_step: float = 1e-12
+    rtol: float = 1e-6
+    atol: float = 1e-9
+    max_steps: int = 100
+    max_current: float = 2e6
+    max_duration: float = 5e-9
+    success_threshold: float = 0.9
+    energy_penalty_weight: float = 0.1
+    target_states: Sequence[Sequence[float]] = field(default_factory=lambda: [[0.0, 0.0, 1.0], [0.0, 0.0, -1.0]])
+    seed: int = 0
+    max_attempts: int = 2_000_000
+    skip_done: bool = False
+
+    def to_abi(self) -> "_lib.StgConfig":
+        if self.solver not in _lib.SOLVERS:
+            raise ValueError(f"Unknown solver '{self.solver}' (expected one of {list(_lib.SOLVERS)})")
+        t = np.asarray(self.target_states, dtype=np.float64).reshape(-1, 3)
+        if not 1 <= len(t) <= _lib.STG_MAX_TARGETS:
+            raise ValueError(f"between 1 and {_lib.STG_MAX_TARGETS} target states are supported")
+        c = _lib.StgConfig()
+        c.solver = _lib.SOLVERS[self.solver]
+        c.thermal = int(bool(self.include_thermal_fluctuations))
+        c.temperature, c.gamma, c.max_step = float(self.temperature), float(self.gamma), float(self.max_step)
+        c.rtol, c.atol = float(self.rtol), float(self.atol)
+        c.max_steps, c.n_targets = int(self.max_steps), len(t)
+        c.max_current, c.max_duration = float(self.max_current), float(self.max_duration)
+        c.success_threshold, c.energy_penalty_weight = float(self.success_threshold), float(self.energy_penalty_weight)
+        for i, row in enumerate(t):
+            for j in range(3):
+                c.targets[i][j] = float(row[j])
+        c.seed = int(self.seed) & 0xFFFFFFFFFFFFFFFF
+        c.max_attempts = int(self.max_attempts)
+        c.skip_done = int(bool(self.skip_done))
+        return c
+
+
+PACKED_BYTES_PER_ENV = 54   # obs 12 x f32 + reward f32 + terminated u8 + truncated u8
+
+
+def packed_step_buffer(n: int, device):
+    """One contiguous uint8 buffer holding a step's RL-facing outputs, and typed views into it:
+    [0, 48n) obs f32[12][n] | [48n, 52n) reward f32[n] | [52n, 53n) terminated u8[n] | [53n, 54n) truncated u8[n]."""
+    buf = torch.zeros(PACKED_BYTES_PER_ENV * n, dtype=torch.uint8, device=device)
+    return buf, unpack_step_buffer(buf, n)
+
+
+def unpack_step_buffer(buf: torch.Tensor, n: int):
+    obs = buf[: 48 * n].view(torch.float32).view(12, n)
+    reward = buf[48 * n: 52 * n].view(torch.float32)
+    return obs, reward, buf[52 * n: 53 * n], buf[53 * n: 54 * n]
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class HipBackend:
+    """Owns one stg_ctx.  All tensors are on ``cuda:<device_index>``; per-env arrays are component-major
+    ([3,N], [12,N], [2,N]) as the C-ABI defines them."""
+
+    def __init__(self, n_envs: int, cfg: EnvConfig, device_index: int = 0, env_id0: int = 0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipBackend needs a visible MI355X (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback for the step path")
+        self.n = int(n_envs)
+        self.cfg = cfg
+        self.device = torch.device("cuda", device_index)
+        self.env_id0 = int(env_id0)
+        self._ctx = C.c_void_p()
+        abi = cfg.to_abi()
+        _lib.check(self.lib.stg_create(C.byref(self._ctx), device_index, self.n, self.env_id0, C.byref(abi)))
+        self._cls = None
+        n = self.n
+        dev = self.device
+        # (obs, reward, terminated, truncated) live in ONE byte buffer -- 54 B/env -- so that the multi-GPU path can
+        # move a step's results with a single RCCL all-gather; the tensors below are views.
+        self.packed, (self.obs, self.reward, self.terminated, self.truncated) = packed_step_buffer(n, dev)
+        self.reward64 = torch.empty(n, dtype=torch.float64, device=dev)
+        self.energy = torch.empty(n, dtype=torch.float64, device=dev)
+        self.status = torch.empty(n, dtype=torch.uint8, device=dev)
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, t, dtype, shape=None):
+        if t is None:
+            return None
+        t = torch.as_tensor(t)
+        t = t.to(device=self.device, dtype=dtype).contiguous()
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return t
+
+    def close(self):
+        if self._ctx:
+            torch.cuda.synchronize(self.device)
+            self.lib.stg_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- parameter surface ------------------------------------------------------------------------
+    def set_params(self, table: List["_lib.StgDeviceParams"], cls=None):
+        arr = (_lib.StgDeviceParams * len(table))(*table)
+        self._cls = self._dev(cls, torch.uint8, (self.n,)) if len(table) > 1 else None
+        if len(table) > 1 and self._cls is None:
+            raise ValueError("a class index per env is required with more than one device class")
+        if self._cls is not None and int(self._cls.max()) >= len(table):
+            raise ValueError("class index out of range")
+        _lib.check(self.lib.stg_set_params(self._ctx, arr, len(table), _ptr(self._cls)))
+        self.n_classes = len(table)
+
+    def thermal_strength(self, cls=0) -> float:
+        out = C.c_double()
+        _lib.check(self.lib.stg_thermal_strength(self._ctx, cls, C.byref(out)))
+        return out.value
+
+    # -- env level ----------------------------------------------------------------------------------
+    def reset(self, mask=None, init_m=None, target=None, seed=0):
+        mask = self._dev(mask, torch.uint8, (self.n,))
+        init_m = self._dev(init_m, torch.float64, (3, self.n))
+        target = self._dev(target, torch.float64, (3, self.n))
+        _lib.check(self.lib.stg_reset(self._ctx, _ptr(mask), _ptr(init_m), _ptr(target),
+                                      int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(self.obs), self._stream()))
+        self._keep = (mask, init_m, target)      # keep inputs alive until the stream has consumed them
+        return self.obs
+
+    def step(self, actions, autoreset=False):
+        """actions: [2,N] float32 or float64 tensor (row 0 current density, row 1 duration).  One kernel launch; the
+        RL-facing outputs land in `self.packed`.  autoreset: envs whose episode ended on the previous step are reset on
+        the device before this one."""
+        a = torch.as_tensor(actions)
+        f64 = a.dtype == torch.float64
+        a = self._dev(a, torch.float64 if f64 else torch.float32, (2, self.n))
+        _lib.check(self.lib.stg_step_many(self._ctx, 1, _ptr(a), int(f64), 1, int(bool(autoreset)), _ptr(self.obs),
+                                          _ptr(self.reward), _ptr(self.reward64), _ptr(self.energy),
+                                          _ptr(self.terminated), _ptr(self.truncated), _ptr(self.status),
+                                          self._stream()))
+        self._keep = (a,)
+        return self.obs, self.reward, self.reward64, self.terminated, self.truncated, self.status
+
+    def step_many(self, actions, out_every=True, autoreset=False):
+        """actions: [K,2,N]; returns tensors with a leading K (out_every) or 1 dimension."""
+        a = torch.as_tensor(actions)
+        f64 = a.dtype == torch.float64
+        K = int(a.shape[0])
+        a = self._dev(a, torch.float64 if f64 else torch.float32, (K, 2, self.n))
+        ko = K if out_every else 1
+        n, dev = self.n, self.device
+        obs = torch.empty((ko, 12, n), dtype=torch.float32, device=dev)
+        reward = torch.empty((ko, n), dtype=torch.float32, device=dev)
+        reward64 = torch.empty((ko, n), dtype=torch.float64, device=dev)
+        term = torch.empty((ko, n), dtype=torch.uint8, device=dev)
+        trunc = torch.empty((ko, n), dtype=torch.uint8, device=dev)
+        status = torch.empty((ko, n), dtype=torch.uint8, device=dev)
+        self.energy_many = torch.empty((ko, n), dtype=torch.float64, device=dev)
+        _lib.check(self.lib.stg_step_many(self._ctx, K, _ptr(a), int(f64), int(bool(out_every)), int(bool(autoreset)),
+                                          _ptr(obs), _ptr(reward), _ptr(reward64), _ptr(self.energy_many), _ptr(term),
+                                          _ptr(trunc), _ptr(status), self._stream()))
+        self._keep = (a,)
+        return obs, reward, reward64, term, trunc, status
+
+    def get_state(self):
+        n, dev = self.n, self.device
+        st = dict(m=torch.empty((3, n), dtype=torch.float64, device=dev),
+                  target=torch.empty((3, n), dtype=torch.float64, device=dev),
+                  total_energy=torch.empty(n, dtype=torch.float64, device=dev),
+                  step_count=torch.empty(n, dtype=torch.int32, device=dev),
+                  rng_step=torch.empty(n, dtype=torch.int32, device=dev),
+                  done=torch.empty(n, dtype=torch.uint8, device=dev))
+        _lib.check(self.lib.stg_get_state(self._ctx, _ptr(st["m"]), _ptr(st["target"]), _ptr(st["total_energy"]),
+                                          _ptr(st["step_count"]), _ptr(st["rng_step"]), _ptr(st["done"]),
+                                          self._stream()))
+        return st
+
+    def set_state(self, st):
+        n = self.n
+        m = self._dev(st.get("m"), torch.float64, (3, n))
+        tg = self._dev(st.get("target"), torch.float64, (3, n))
+        e = self._dev(st.get("total_energy"), torch.float64, (n,))
+        sc = self._dev(st.get("step_count"), torch.int32, (n,))
+        rs = self._dev(st.get("rng_step"), torch.int32, (n,))
+        dn = self._dev(st.get("done"), torch.uint8, (n,))
+        _lib.check(self.lib.stg_set_state(self._ctx, _ptr(m), _ptr(tg), _ptr(e), _ptr(sc), _ptr(rs), _ptr(dn),
+                                          self._stream()))
+        self._keep = (m, tg, e, sc, rs, dn)
+
+    # -- solver level -------------------------------------------------------------------------------
+    def solve(self, m0, J, T, env_step=0, traj_cap=0, want_energy=False):
+        n, dev = self.n, self.device
+        m0 = self._dev(m0, torch.float64, (3, n))
+        J = self._dev(J, torch.float64, (n,))
+        T = self._dev(T, torch.float64, (n,))
+        mf = torch.empty((3, n), dtype=torch.float64, device=dev)
+        npts = torch.empty(n, dtype=torch.int32, device=dev)
+        succ = torch.empty(n, dtype=torch.uint8, device=dev)
+        out = dict(m_final=mf, n_points=npts, success=succ)
+        if traj_cap > 0:
+            t = torch.zeros((traj_cap, n), dtype=torch.float64, device=dev)
+            m = torch.zeros((traj_cap, 3, n), dtype=torch.float64, device=dev)
+            e = torch.zeros((traj_cap, n), dtype=torch.float64, device=dev) if want_energy else None
+            _lib.check(self.lib.stg_solve_traj(self._ctx, _ptr(m0), _ptr(J), _ptr(T), int(env_step), int(traj_cap),
+                                               _ptr(t), _ptr(m), _ptr(e), _ptr(mf), _ptr(npts), _ptr(succ),
+                                               self._stream()))
+            out.update(t=t, m=m, energy=e)
+        else:
+            _lib.check(self.lib.stg_solve(self._ctx, _ptr(m0), _ptr(J), _ptr(T), int(env_step), _ptr(mf),
+                                          _ptr(npts), _ptr(succ), self._stream()))
+        self._keep = (m0, J, T)
+        return out
+
+    def counters(self, reset=False):
+        """On-device metrics: dict(env_steps, work_units, noop_steps).  Synchronises the device."""
+        out = (C.c_uint64 * 4)()
+        _lib.check(self.lib.stg_get_counters(self._ctx, out, int(bool(reset))))
+        return {"env_steps": int(out[0]), "work_units": int(out[1]), "noop_steps": int(out[3])}
+
+    def thermal_normals(self, env_step=0, call0=0, n_calls=1):
+        z = torch.empty((n_calls, 3, self.n), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.stg_thermal_normals(self._ctx, int(env_step), int(call0), int(n_calls), _ptr(z),
+                                                self._stream()))
+        return z

@@ -1,0 +1,315 @@
+"""Device parameter surface: the `spin_torque_gym.devices` API the env path consumes.
+
+Mirrors (same names, argument meaning and error behaviour):
+  DeviceFactory ............ spin_torque_gym/devices/device_factory.py:18-194
+  BaseSpintronicDevice ..... spin_torque_gym/devices/base_device.py:13-138
+  STTMRAMDevice ............ spin_torque_gym/devices/stt_mram.py:16-98
+  SOTMRAMDevice ............ spin_torque_gym/devices/sot_mram.py:16-228 (parameters, resistance, torque factors)
+  VCMAMRAMDevice ........... spin_torque_gym/devices/vcma_mram.py:16-257 (parameters, resistance, K_eff)
+
+The env only reads ``device.device_params``, ``get_parameter`` and ``compute_resistance``
+(spin_torque_env.py:454,475,501); on the GPU path those values travel as one flattened
+``stg_device_params`` record per device class (`flatten_params`) and the resistance is evaluated in the
+step kernel.  The host-side ``compute_resistance`` here is API surface for user code (analysis, tests), it is
+never called from step()/reset().  Skyrmion devices are out of scope (different physics).
+"""
+import warnings
+from typing import Any, Dict
+
+import numpy as np
+
+from . import _lib
+
+MU0 = 4 * np.pi * 1e-7
+
+
+class BaseSpintronicDevice:
+    """Common parameter handling (base_device.py:13-138)."""
+
+    device_type = "base"
+    _required = ("volume", "saturation_magnetization")
+
+    def __init__(self, device_params: Dict[str, Any]):
+        self.device_params = device_params.copy()
+        self.volume = device_params.get("volume", 1e-24)
+        self.thickness = device_params.get("thickness", 1e-9)
+        self.saturation_magnetization = device_params.get("saturation_magnetization", 800e3)
+        self.mu0 = MU0
+        self.kb = 1.380649e-23
+        self.e = 1.602176634e-19
+        self.hbar = 1.054571817e-34
+        self._validate_parameters()
+
+    def _validate_parameters(self) -> None:
+        for key in self._required:
+            if key not in self.device_params:
+                raise ValueError(f"Missing required parameter: {key}")
+
+    def get_parameter(self, key: str, default: Any = None) -> Any:
+        return self.device_params.get(key, default)
+
+    def set_parameter(self, key: str, value: Any) -> None:
+        self.device_params[key] = value
+
+    def validate_magnetization(self, magnetization) -> np.ndarray:
+        """base_device.py:94-116: unit vector or ValueError."""
+        if not isinstance(magnetization, np.ndarray):
+            magnetization = np.array(magnetization)
+        if magnetization.shape != (3,):
+            raise ValueError(f"Magnetization must be 3D vector, got shape {magnetization.shape}")
+        magnitude = np.linalg.norm(magnetization)
+        if magnitude < 1e-12:
+            raise ValueError("Magnetization vector cannot be zero")
+        return magnetization / magnitude
+
+    def _reference_layer(self) -> np.ndarray:
+        ref = np.asarray(self.device_params.get("reference_magnetization", np.array([0, 0, 1])), dtype=float)
+        return ref / np.linalg.norm(ref)
+
+    def compute_resistance(self, magnetization: np.ndarray) -> float:
+        raise NotImplementedError
+
+    def get_device_info(self) -> Dict[str, Any]:
+        return {
+            "device_type": self.__class__.__name__,
+            "volume": self.volume,
+            "thickness": self.thickness,
+            "saturation_magnetization": self.saturation_magnetization,
+            "parameters": self.device_params.copy(),
+        }
+
+    def __repr__(self) -> str:
+        return f"{self.__class__.__name__}(volume={self.volume:.2e}, Ms={self.saturation_magnetization:.0f})"
+
+
+class STTMRAMDevice(BaseSpintronicDevice):
+    """stt_mram.py:16-98."""
+
+    device_type = "stt_mram"
+    _required = ("volume", "saturation_magnetization", "damping", "uniaxial_anisotropy", "polarization")
+
+    def __init__(self, device_params):
+        super().__init__(device_params)
+        self.reference_magnetization = self.validate_magnetization(
+            self.get_parameter("reference_magnetization", np.array([0, 0, 1])))
+
+    def _validate_parameters(self) -> None:
+        super()._validate_parameters()
+        p = self.device_params
+        if p["volume"] <= 0:
+            raise ValueError("Volume must be positive")
+        if p["saturation_magnetization"] <= 0:
+            raise ValueError("Saturation magnetization must be positive")
+        if not 0 <= p["damping"] <= 1:
+            raise ValueError("Damping must be between 0 and 1")
+        if not 0 <= p["polarization"] <= 1:
+            raise ValueError("Polarization must be between 0 and 1")
+
+    def compute_resistance(self, magnetization) -> float:
+        """stt_mram.py:78-94: R_P (1 + TMR (1 - cos)/2), floor R_P/2; the input is re-normalised."""
+        m = self.validate_magnetization(magnetization)
+        r_p = self.get_parameter("resistance_parallel", 1e3)
+        r_ap = self.get_parameter("resistance_antiparallel", 2e3)
+        tmr = (r_ap - r_p) / r_p
+        r = r_p * (1 + tmr * (1 - np.dot(m, self.reference_magnetization)) / 2)
+        return max(r, r_p * 0.5)
+
+
+class SOTMRAMDevice(BaseSpintronicDevice):
+    """sot_mram.py:16-228 (parameter surface, torque efficiency factors, resistance)."""
+
+    device_type = "sot_mram"
+    _required = ("volume", "saturation_magnetization", "damping", "uniaxial_anisotropy", "easy_axis")
+
+    def __init__(self, device_params):
+        super().__init__(device_params)
+        p = device_params
+        if p.get("spin_hall_angle", 0.1) > 1.0:
+            warnings.warn("Spin Hall angle > 1.0 is physically unrealistic")
+        self.spin_hall_angle = p.get("spin_hall_angle", 0.1)
+        self.heavy_metal_thickness = p.get("heavy_metal_thickness", 5e-9)
+        self.heavy_metal_resistivity = p.get("heavy_metal_resistivity", 2e-7)
+        self.interface_transparency = p.get("interface_transparency", 0.5)
+        self.field_like_efficiency = p.get("field_like_efficiency", 0.1)
+        self.damping_like_efficiency = p.get("damping_like_efficiency", 0.2)
+        # sot_mram.py:61-77
+        self.j_s_efficiency = (self.spin_hall_angle * self.interface_transparency
+                               * (self.heavy_metal_thickness / (self.heavy_metal_thickness + self.thickness)))
+        self.tau_dl_factor = self.damping_like_efficiency * self.j_s_efficiency
+        self.tau_fl_factor = self.field_like_efficiency * self.j_s_efficiency
+        self.sheet_resistance_hm = self.heavy_metal_resistivity / self.heavy_metal_thickness
+        self.area = p.get("area", self.volume / self.thickness)
+
+    def series_resistance(self) -> float:
+        """0.1 * r_hm with r_hm = sheet_resistance_hm / (area * 1e-12) (sot_mram.py:218-223)."""
+        return (self.sheet_resistance_hm / (self.area * 1e-12)) * 0.1
+
+    def compute_resistance(self, magnetization) -> float:
+        """sot_mram.py:196-228: R_P + (R_AP - R_P)(1 - cos)/2 + 0.1 r_hm, floor 1; no re-normalisation."""
+        r_p = self.device_params.get("resistance_parallel", 1e3)
+        r_ap = self.device_params.get("resistance_antiparallel", 2e3)
+        r_mtj = r_p + (r_ap - r_p) * (1 - np.dot(magnetization, self._reference_layer())) / 2
+        return max(r_mtj + self.series_resistance(), 1.0)
+
+    def compute_spin_torque(self, current_density, magnetization, current_direction=None):
+        """sot_mram.py:163-194: tau_DL = f_dl J (sigma x m), tau_FL = f_fl J sigma, sigma = z x j_hat."""
+        j_hat = np.array([1.0, 0.0, 0.0]) if current_direction is None else np.asarray(current_direction, dtype=float)
+        j_hat = j_hat / np.linalg.norm(j_hat)
+        sigma = np.cross(np.array([0.0, 0.0, 1.0]), j_hat)
+        return (self.tau_dl_factor * current_density * np.cross(sigma, magnetization),
+                self.tau_fl_factor * current_density * sigma)
+
+
+class VCMAMRAMDevice(BaseSpintronicDevice):
+    """vcma_mram.py:16-257 (parameter surface, effective anisotropy, resistance)."""
+
+    device_type = "vcma_mram"
+    _required = ("volume", "saturation_magnetization", "damping", "uniaxial_anisotropy", "easy_axis")
+
+    def __init__(self, device_params):
+        super().__init__(device_params)
+        p = device_params
+        if p.get("vcma_coefficient", 100e-6) < 0:
+            warnings.warn("Negative VCMA coefficient indicates inverted VCMA effect")
+        self.vcma_coefficient = p.get("vcma_coefficient", 100e-6)
+        self.dielectric_thickness = p.get("dielectric_thickness", 1e-9)
+        self.dielectric_constant = p.get("dielectric_constant", 25.0)
+        self.breakdown_voltage = p.get("breakdown_voltage", 2.0)
+        self.leakage_resistance = p.get("leakage_resistance", 1e12)
+        self.area = p.get("area", self.volume / self.thickness)
+        self.base_anisotropy = p["uniaxial_anisotropy"]
+
+    def effective_anisotropy(self, voltage: float) -> float:
+        """vcma_mram.py:122-147: K - xi |V| / t_d^2, V clipped to +-V_bd, floor -K/2."""
+        v = float(np.clip(voltage, -self.breakdown_voltage, self.breakdown_voltage))
+        k_eff = self.base_anisotropy - self.vcma_coefficient * abs(v) / (self.dielectric_thickness ** 2)
+        return max(k_eff, -0.5 * self.base_anisotropy)
+
+    _compute_effective_anisotropy = effective_anisotropy
+
+    def compute_resistance(self, magnetization) -> float:
+        """vcma_mram.py:236-257: R_P + (R_AP - R_P)(1 - cos)/2, floor 1; no re-normalisation."""
+        r_p = self.device_params.get("resistance_parallel", 1e3)
+        r_ap = self.device_params.get("resistance_antiparallel", 2e3)
+        r = r_p + (r_ap - r_p) * (1 - np.dot(magnetization, self._reference_layer())) / 2
+        return max(r, 1.0)
+
+
+_DEFAULTS = {
+    # device_factory.py:129-172 (values are data)
+    "stt_mram": lambda: {
+        "volume": 50e-9 * 100e-9 * 2e-9, "area": 50e-9 * 100e-9, "thickness": 2e-9, "aspect_ratio": 2.0,
+        "saturation_magnetization": 800e3, "damping": 0.01, "uniaxial_anisotropy": 1.2e6,
+        "exchange_constant": 20e-12, "polarization": 0.7, "resistance_parallel": 1e3,
+        "resistance_antiparallel": 2e3, "easy_axis": np.array([0, 0, 1]),
+        "reference_magnetization": np.array([0, 0, 1])},
+    "sot_mram": lambda: {
+        "volume": 100e-9 * 100e-9 * 1e-9, "area": 100e-9 * 100e-9, "thickness": 1e-9,
+        "saturation_magnetization": 800e3, "damping": 0.015, "uniaxial_anisotropy": 0.8e6,
+        "exchange_constant": 20e-12, "spin_hall_angle": 0.2, "resistance_parallel": 500,
+        "resistance_antiparallel": 1000, "easy_axis": np.array([0, 0, 1])},
+    "vcma_mram": lambda: {
+        "volume": 80e-9 * 80e-9 * 1.5e-9, "area": 80e-9 * 80e-9, "thickness": 1.5e-9,
+        "saturation_magnetization": 800e3, "damping": 0.008, "uniaxial_anisotropy": 1.5e6,
+        "exchange_constant": 20e-12, "vcma_coefficient": 100e-6, "resistance_parallel": 2e3,
+        "resistance_antiparallel": 4e3, "easy_axis": np.array([0, 0, 1])},
+}
+_GENERIC = lambda: {"volume": 1e-24, "saturation_magnetization": 800e3, "damping": 0.01,  # noqa: E731
+                    "uniaxial_anisotropy": 1e6, "exchange_constant": 20e-12, "polarization": 0.7}
+
+
+class DeviceFactory:
+    """device_factory.py:18-194."""
+
+    def __init__(self):
+        self._device_types = {}
+        for name, cls in (("stt_mram", STTMRAMDevice), ("sot_mram", SOTMRAMDevice), ("vcma_mram", VCMAMRAMDevice)):
+            self.register_device(name, cls)
+
+    def register_device(self, device_type: str, device_class) -> None:
+        if not (isinstance(device_class, type) and issubclass(device_class, BaseSpintronicDevice)):
+            raise ValueError("Device class must inherit from BaseSpintronicDevice")
+        self._device_types[device_type.lower()] = device_class
+
+    def create_device(self, device_type: str, device_params: Dict[str, Any]) -> BaseSpintronicDevice:
+        device_type = device_type.lower()
+        if device_type not in self._device_types:
+            raise ValueError(f"Unknown device type '{device_type}'. Available types: {list(self._device_types)}")
+        try:
+            return self._device_types[device_type](device_params)
+        except Exception as e:      # device_factory.py:74-77
+            raise RuntimeError(f"Failed to create {device_type} device: {e}")
+
+    def get_available_devices(self) -> list:
+        return list(self._device_types)
+
+    def get_device_info(self, device_type: str) -> Dict[str, Any]:
+        device_type = device_type.lower()
+        if device_type not in self._device_types:
+            raise ValueError(f"Unknown device type '{device_type}'")
+        cls = self._device_types[device_type]
+        return {"name": device_type, "class": cls.__name__, "module": cls.__module__, "docstring": cls.__doc__}
+
+    def get_default_parameters(self, device_type: str) -> Dict[str, Any]:
+        return _DEFAULTS.get(device_type.lower(), _GENERIC)()
+
+    def create_default_device(self, device_type: str) -> BaseSpintronicDevice:
+        return self.create_device(device_type, self.get_default_parameters(device_type))
+
+
+def params_valid_as_stt(d: Dict[str, Any]) -> bool:
+    """Outcome of ``validate_parameters(device_params)`` as RobustLLGSSolver calls it, i.e. with the default
+    ``device_type='stt_mram'`` whatever the device is (utils/validation.py:176-234,491-493;
+    utils/robust_solver.py:179).  False -> every solve falls back and the step is a no-op on m."""
+    def positive(v, lo):
+        try:
+            v = float(v)
+        except (TypeError, ValueError):
+            return False
+        return bool(np.isfinite(v) and v > 0 and v >= lo)
+
+    def probability(v):
+        try:
+            v = float(v)
+        except (TypeError, ValueError):
+            return False
+        return bool(np.isfinite(v) and 0 <= v <= 1)
+
+    for key in ("volume", "saturation_magnetization", "damping", "uniaxial_anisotropy", "easy_axis", "polarization"):
+        if key not in d:
+            return False
+    try:
+        e = np.array(d["easy_axis"], dtype=float)
+    except (TypeError, ValueError):
+        return False
+    if e.shape != (3,) or not np.all(np.isfinite(e)) or np.linalg.norm(e) < 1e-12:
+        return False
+    return (positive(d["volume"], 1e-30) and positive(d["saturation_magnetization"], 1e3)
+            and probability(d["damping"]) and positive(d["uniaxial_anisotropy"], 1e3)
+            and probability(d["polarization"]))
+
+
+def flatten_params(device: BaseSpintronicDevice) -> "_lib.StgDeviceParams":
+    """One reference-style device -> the C-ABI record (include/spintorque_hip.h: stg_device_params), using the
+    defaults of the reference's own .get() calls (simple_solver.py:126-131; llgs_solver.py:79-82,192-205;
+    spin_torque_env.py:476,502)."""
+    d = device.device_params
+    p = _lib.StgDeviceParams()
+    p.damping = d.get("damping", 0.01)
+    p.ms = d.get("saturation_magnetization", 800e3)
+    p.ku = d.get("uniaxial_anisotropy", 1e6)
+    p.volume = d.get("volume", 1e-24)
+    p.polarization = d.get("polarization", 0.7)
+    p.easy_axis[:] = [float(x) for x in np.asarray(d.get("easy_axis", [0, 0, 1]), dtype=float)]
+    p.demag[:] = [float(x) for x in np.asarray(d.get("demag_factors", [0, 0, 1]), dtype=float)]
+    p.a_ex = d.get("exchange_constant", 20e-12)
+    p.area = d.get("area", 1e-14)
+    p.r_p = d.get("resistance_parallel", 1e3)
+    p.r_ap = d.get("resistance_antiparallel", 2e3)
+    p.ref_m[:] = [float(x) for x in np.asarray(d.get("reference_magnetization", [0, 0, 1]), dtype=float)]
+    p.r_series = device.series_resistance() if isinstance(device, SOTMRAMDevice) else 0.0
+    if device.device_type not in _lib.DEV_TYPES:
+        raise ValueError(f"device type '{device.device_type}' is not supported on the GPU step path")
+    p.dev_type = _lib.DEV_TYPES[device.device_type]
+    p.params_valid = int(params_valid_as_stt(d))
+    return p

@@ -1,0 +1,419 @@
+"""Environment level: the Gymnasium-facing mirror of the reference's SpinTorqueEnv.
+
+  SpinTorqueVecEnv ... N independent SpinTorque-v0 environments stepped by one kernel launch; torch tensors in
+                       and out (VectorEnv-shaped API).  This is the product.
+  SpinTorqueEnv ...... the reference's single-env class as a thin N=1 facade over the same kernels: same
+                       constructor keywords, reset/step/render/close, info keys and error behaviour as
+                       spin_torque_gym/envs/spin_torque_env.py:26-745, NumPy in and out.
+
+Nothing here computes physics: action clamping, integration, energy, observation, reward and termination all
+happen in libspintorque_hip.so.  The host side keeps what is inherently host-side in the reference too:
+the seeded PCG64 generator of reset() (gymnasium.utils.seeding), the episode history list and rendering.
+"""
+import warnings
+from typing import Any, Dict, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from .backend import EnvConfig, HipBackend
+from .devices import DeviceFactory, flatten_params
+
+try:  # Gymnasium is optional (it is not part of the build image); the API shape is kept either way.
+    import gymnasium as _gym
+    from gymnasium import spaces as _spaces
+    _EnvBase = _gym.Env
+except Exception:  # pragma: no cover - exercised in the build image
+    _gym = None
+    _spaces = None
+    _EnvBase = object
+
+
+class _Box:
+    """Minimal stand-in for gymnasium.spaces.Box when Gymnasium is absent (attributes only)."""
+
+    def __init__(self, low, high, shape=None, dtype=np.float32):
+        low = np.asarray(low, dtype=dtype)
+        high = np.asarray(high, dtype=dtype)
+        self.shape = tuple(shape) if shape is not None else low.shape
+        self.low = np.broadcast_to(low, self.shape).astype(dtype)
+        self.high = np.broadcast_to(high, self.shape).astype(dtype)
+        self.dtype = np.dtype(dtype)
+        self._rng = np.random.default_rng()
+
+    def seed(self, seed=None):
+        self._rng = np.random.default_rng(seed)
+
+    def sample(self):
+        lo = np.where(np.isfinite(self.low), self.low, -1.0)
+        hi = np.where(np.isfinite(self.high), self.high, 1.0)
+        return self._rng.uniform(lo, hi).astype(self.dtype)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+
+def _box(low, high, shape=None, dtype=np.float32):
+    if _spaces is not None:
+        return _spaces.Box(low=np.asarray(low, dtype=dtype) if shape is None else low,
+                           high=np.asarray(high, dtype=dtype) if shape is None else high, shape=shape, dtype=dtype)
+    return _Box(low, high, shape, dtype)
+
+
+def _np_random(seed=None):
+    """gymnasium.utils.seeding.np_random: Generator(PCG64(SeedSequence(seed)))."""
+    ss = np.random.SeedSequence(seed)
+    return np.random.Generator(np.random.PCG64(ss)), ss.entropy
+
+
+def _default_env_side_params(device_type: str) -> Dict[str, Any]:
+    """SpinTorqueEnv._get_default_device_params (spin_torque_env.py:156-182): the factory's STT defaults, or a
+    generic dict for other types (which lacks 'easy_axis', so the factory then rejects it, as in the reference)."""
+    if device_type == "stt_mram":
+        return DeviceFactory().get_default_parameters("stt_mram")
+    return {"volume": 1e-24, "saturation_magnetization": 800e3, "damping": 0.01, "uniaxial_anisotropy": 1e6,
+            "polarization": 0.7}
+
+
+class SpinTorqueVecEnv:
+    """N parallel SpinTorque-v0 environments on one MI355X.
+
+    Device classes: pass one ``device_type``/``device_params`` for a homogeneous batch, or lists of both plus
+    ``class_index`` (uint8 per env) for mixed batches (up to 64 classes; the per-class constants live in LDS).
+    Layout: ``obs`` is returned as an [N,12] *view* of the kernel's component-major [12,N] buffer (no copy);
+    actions are accepted as [N,2] (Gym convention) or, with ``actions_soa=True``, as the kernel's [2,N].
+    """
+
+    def __init__(self, num_envs: int, device_type: Union[str, Sequence[str]] = "stt_mram",
+                 device_params: Union[None, Dict[str, Any], Sequence[Dict[str, Any]]] = None,
+                 class_index=None, target_states: Optional[List[np.ndarray]] = None, max_steps: int = 100,
+                 max_current: float = 2e6, max_duration: float = 5e-9, temperature: float = 300.0,
+                 include_thermal_fluctuations: bool = True, success_threshold: float = 0.9,
+                 energy_penalty_weight: float = 0.1, solver: str = "rk4", seed: Optional[int] = None,
+                 autoreset: bool = False, skip_done: bool = False, device_index: int = 0, env_id0: int = 0,
+                 max_attempts: int = 2_000_000, backend=None):
+        self.num_envs = int(num_envs)
+        factory = DeviceFactory()
+        types = [device_type] if isinstance(device_type, str) else list(device_type)
+        if device_params is None:
+            plist = [_default_env_side_params(t) for t in types]
+        elif isinstance(device_params, dict):
+            plist = [device_params]
+        else:
+            plist = list(device_params)
+        if len(plist) != len(types):
+            raise ValueError("device_type and device_params must have the same length")
+        self.devices = [factory.create_device(t, p) for t, p in zip(types, plist)]
+        self.device_types = types
+        if target_states is None:
+            targets = [np.array([0.0, 0.0, 1.0]), np.array([0.0, 0.0, -1.0])]
+        else:
+            targets = [self.devices[0].validate_magnetization(np.asarray(t, dtype=float)) for t in target_states]
+        self.target_states = targets
+        self._rng, self._seed = _np_random(seed)
+        self.cfg = EnvConfig(solver=solver, include_thermal_fluctuations=include_thermal_fluctuations,
+                             temperature=temperature, max_steps=max_steps, max_current=max_current,
+                             max_duration=max_duration, success_threshold=success_threshold,
+                             energy_penalty_weight=energy_penalty_weight, target_states=[list(t) for t in targets],
+                             seed=int(self._rng.integers(0, 2**63 - 1)) if seed is None else int(seed),
+                             max_attempts=max_attempts, skip_done=skip_done)
+        self.autoreset = bool(autoreset)
+        # `backend` is a test seam: a class/callable with HipBackend's constructor signature (tests inject the CPU
+        # oracle for the gloo runs and as the comparator); the product default is the HIP library, nothing else.
+        factory_fn = HipBackend if backend is None else backend
+        self.backend = factory_fn(self.num_envs, self.cfg, device_index, env_id0)
+        self.backend.set_params([flatten_params(d) for d in self.devices], class_index)
+        self.single_action_space = _box([-max_current, 0.0], [max_current, max_duration], dtype=np.float32)
+        self.single_observation_space = _box(-np.inf, np.inf, shape=(12,), dtype=np.float32)
+        self._needs_reset = True
+
+    # -- Gymnasium VectorEnv-shaped API ---------------------------------------------------------------
+    def reset(self, seed: Optional[int] = None, options: Optional[Dict[str, Any]] = None):
+        """options: 'initial_state' / 'target_state' as [N,3] (or [3], broadcast) arrays, 'mask' (bool [N]) to
+        reset a subset.  Without them states are drawn on the device from Philox(seed, env_id, ...)."""
+        options = options or {}
+        if seed is not None:
+            self._rng, self._seed = _np_random(seed)
+        dev_seed = int(self._rng.integers(0, 2**63 - 1))
+        init = self._soa3(options.get("initial_state"))
+        tgt = self._soa3(options.get("target_state"))
+        mask = options.get("mask")
+        if mask is not None:
+            mask = torch.as_tensor(mask).to(torch.uint8)
+        obs = self.backend.reset(mask, init, tgt, dev_seed)
+        self._needs_reset = False
+        return obs.t(), {}
+
+    def step(self, actions, actions_soa: bool = False):
+        if self._needs_reset:
+            raise RuntimeError("Environment must be reset before calling step")
+        a = torch.as_tensor(actions)
+        if not actions_soa:
+            a = a.t()
+        obs, rew, rew64, term, trunc, status = self.backend.step(a, autoreset=self.autoreset)
+        energy = self.backend.energy
+        return obs.t(), rew, term.bool(), trunc.bool(), {"status": status, "reward_f64": rew64, "energy": energy}
+
+    def step_many(self, actions, out_every: bool = True, actions_soa: bool = False):
+        """K env steps in one launch.  actions [K,N,2] (or [K,2,N] with actions_soa)."""
+        a = torch.as_tensor(actions)
+        if not actions_soa:
+            a = a.transpose(1, 2)
+        obs, rew, rew64, term, trunc, status = self.backend.step_many(a, out_every=out_every, autoreset=self.autoreset)
+        return obs.transpose(1, 2), rew, term.bool(), trunc.bool(), {"status": status, "reward_f64": rew64,
+                                                                      "energy": self.backend.energy_many}
+
+    def _soa3(self, v):
+        if v is None:
+            return None
+        t = torch.as_tensor(np.asarray(v, dtype=np.float64) if not torch.is_tensor(v) else v).to(torch.float64)
+        if t.dim() == 1:
+            t = t.unsqueeze(0).expand(self.num_envs, 3)
+        if tuple(t.shape) != (self.num_envs, 3):
+            raise ValueError(f"expected [N,3] or [3], got {tuple(t.shape)}")
+        return t.t().contiguous()
+
+    # -- checkpoint / resume ---------------------------------------------------------------------------
+    def state_dict(self):
+        st = {k: v.cpu() for k, v in self.backend.get_state().items()}
+        st["host_rng"] = self._rng.bit_generator.state
+        return st
+
+    def load_state_dict(self, st):
+        self.backend.set_state({k: v for k, v in st.items() if k != "host_rng"})
+        if "host_rng" in st:
+            self._rng.bit_generator.state = st["host_rng"]
+        self._needs_reset = False
+
+    def get_state(self):
+        return self.backend.get_state()
+
+    def close(self):
+        self.backend.close()
+
+
+class SpinTorqueEnv(_EnvBase):
+    """Drop-in for spin_torque_gym.envs.SpinTorqueEnv (spin_torque_env.py:26-745) running on the GPU path.
+
+    Same keyword arguments; two additions select what the reference cannot express: ``solver`` ('rk4' is the
+    SimpleLLGSSolver/RobustLLGSSolver pair the reference env really uses, 'rk45' the LLGSSolver the north star
+    names) and ``device_index``.  Known reference behaviours are reproduced, not repaired:
+    solver failure leaves m unchanged but still charges energy (H3), the energy "penalty" is a bonus (H7),
+    action_mode='discrete' and observation_mode='dict' end in the catch-all error return (H8).  Not reproduced:
+    the result/observation caches (H1/H2), which return stale data.
+    """
+
+    metadata = {"render_modes": ["human", "rgb_array"], "render_fps": 30}
+
+    def __init__(self, device_type: str = "stt_mram", device_params: Optional[Dict[str, Any]] = None,
+                 target_states: Optional[List[np.ndarray]] = None, max_steps: int = 100, max_current: float = 2e6,
+                 max_duration: float = 5e-9, temperature: float = 300.0, include_thermal_fluctuations: bool = True,
+                 reward_components: Optional[Dict[str, Dict]] = None, action_mode: str = "continuous",
+                 observation_mode: str = "vector", success_threshold: float = 0.9, energy_penalty_weight: float = 0.1,
+                 render_mode: Optional[str] = None, seed: Optional[int] = None, solver: str = "rk4",
+                 device_index: int = 0, backend=None):
+        if reward_components is not None:
+            raise NotImplementedError("custom reward callables are arbitrary Python and stay on the reference "
+                                      "(SURVEY.md section 2); the GPU path implements the default 4-component reward")
+        if action_mode not in ("continuous", "discrete"):
+            raise ValueError(f"Unknown action mode: {action_mode}")
+        if observation_mode not in ("vector", "dict"):
+            raise ValueError(f"Unknown observation mode: {observation_mode}")
+        self.device_type = device_type
+        self.max_steps, self.max_current, self.max_duration = max_steps, max_current, max_duration
+        self.temperature, self.include_thermal = temperature, include_thermal_fluctuations
+        self.action_mode, self.observation_mode = action_mode, observation_mode
+        self.success_threshold, self.energy_penalty_weight = success_threshold, energy_penalty_weight
+        self.render_mode = render_mode
+        self._np_random = None
+        self.seed(seed)
+        self._vec = SpinTorqueVecEnv(1, device_type, device_params, None, target_states, max_steps, max_current,
+                                     max_duration, temperature, include_thermal_fluctuations, success_threshold,
+                                     energy_penalty_weight, solver, seed if seed is not None else 0, False, False,
+                                     device_index, 0, backend=backend)
+        self.device = self._vec.devices[0]
+        self.target_states = self._vec.target_states
+        self.solver_name = solver
+        if action_mode == "continuous":
+            self.action_space = _box([-max_current, 0.0], [max_current, max_duration], dtype=np.float32)
+        else:
+            self.current_levels = np.linspace(-max_current, max_current, 5)
+            self.duration_levels = np.array([0.1e-9, 0.5e-9, 1.0e-9, 2.0e-9])
+            self.action_space = _spaces.Discrete(20) if _spaces is not None else None
+        self.observation_space = _box(-np.inf, np.inf, shape=(12,), dtype=np.float32)
+        self.current_magnetization = None
+        self.target_magnetization = None
+        self.step_count = 0
+        self.total_energy = 0.0
+        self.episode_history: List[Dict[str, Any]] = []
+        self.last_action = np.zeros(2)
+        self._solve_count = 0
+        self.renderer = None
+
+    # -- seeding (spin_torque_env.py:694-697) -------------------------------------------------------------
+    def seed(self, seed: Optional[int] = None):
+        self._np_random, s = _np_random(seed)
+        return [s]
+
+    # -- reset (spin_torque_env.py:250-308) -----------------------------------------------------------------
+    def reset(self, seed: Optional[int] = None, options: Optional[Dict[str, Any]] = None):
+        if seed is not None:
+            self._np_random, _ = _np_random(seed)
+        options = options or {}
+        self.step_count, self.total_energy = 0, 0.0
+        self.episode_history = []
+        self.last_action = np.zeros(2)
+        if "initial_state" in options:
+            m0 = self.device.validate_magnetization(options["initial_state"])
+        else:
+            m0 = self.device.validate_magnetization(self._np_random.normal(0, 1, 3))
+        if "target_state" in options:
+            tgt = self.device.validate_magnetization(options["target_state"])
+        else:
+            tgt = self.target_states[self._np_random.integers(len(self.target_states))].copy()
+        obs, _ = self._vec.reset(options={"initial_state": np.asarray(m0, dtype=np.float64)[None, :],
+                                          "target_state": np.asarray(tgt, dtype=np.float64)[None, :]})
+        self._pull_state()
+        return obs[0].cpu().numpy().copy(), self._get_info()
+
+    def _pull_state(self):
+        st = self._vec.get_state()
+        self.current_magnetization = st["m"][:, 0].cpu().numpy().copy()
+        self.target_magnetization = st["target"][:, 0].cpu().numpy().copy()
+        self.total_energy = float(st["total_energy"][0])
+        self.step_count = int(st["step_count"][0])
+
+    # -- step (spin_torque_env.py:310-407) ------------------------------------------------------------------
+    def step(self, action):
+        if self.current_magnetization is None:
+            raise RuntimeError("Environment must be reset before calling step")
+        try:
+            if self.action_mode != "continuous" or self.observation_mode != "vector":
+                # H8: the reference's safety wrapper rejects these modes' inputs and the catch-all takes over
+                raise TypeError("only length-1 arrays can be converted to Python scalars")
+            a = action if isinstance(action, np.ndarray) else np.array(action, dtype=np.float32)
+            if a.shape != (2,):                     # monitoring.py:300-302
+                a = np.array([0.0, 1e-12], dtype=np.float32)
+            if a.dtype not in (np.float32, np.float64):
+                a = a.astype(np.float32)
+            prev_alignment = float(np.dot(self.current_magnetization, self.target_magnetization))
+            obs, rew, term, trunc, info_t = self._vec.step(torch.from_numpy(np.ascontiguousarray(a)).unsqueeze(0))
+            obs_np = obs[0].cpu().numpy().copy()
+            reward = float(info_t["reward_f64"][0])
+            status = int(info_t["status"][0])
+            energy = float(info_t["energy"][0])
+            self._pull_state()
+            self._solve_count += 1
+            # the kernel's parsed action comes back through the observation; recompute it in fp64 for `info`
+            J, T = _parse_action_host(a, self.max_current, self.max_duration)
+            self.last_action = np.array([J, T])
+            alignment = float(np.dot(self.current_magnetization, self.target_magnetization))
+            terminated, truncated = bool(term[0]), bool(trunc[0])
+            self.episode_history.append({"step": self.step_count, "action": [J, T],
+                                         "magnetization": self.current_magnetization.copy(), "reward": reward,
+                                         "energy": energy, "alignment": alignment})
+            info = self._get_info()
+            info.update({"final_magnetization": self.current_magnetization.copy(), "energy_consumed": energy,
+                         "pulse_duration": T, "current_density": J,
+                         "simulation_success": status != _lib.STATUS_NOOP})
+            info.update({"is_success": terminated, "step_energy": energy,
+                         "alignment_improvement": alignment - prev_alignment, "current_alignment": alignment})
+            success_c = 10.0 if terminated else 0.0
+            info.update({"reward_components": {"success": success_c, "energy": -energy / 1e-12,
+                                               "progress": alignment - prev_alignment, "stability": 0.0},
+                         "total_reward": reward, "solver_status": status})
+            return obs_np, reward, terminated, truncated, info
+        except Exception as e:                      # spin_torque_env.py:397-407
+            obs = self._vec.backend.obs[:, 0].cpu().numpy().copy()
+            return obs, -1.0, False, True, {"error": str(e), "step_count": self.step_count}
+
+    def _get_info(self):
+        align = float(np.dot(self.current_magnetization, self.target_magnetization)) if self.current_magnetization is not None else 0.0
+        return {"step_count": self.step_count, "total_energy": self.total_energy, "current_alignment": align,
+                "is_success": align >= self.success_threshold, "target_reached": align >= self.success_threshold,
+                "magnetization_magnitude": float(np.linalg.norm(self.current_magnetization)) if self.current_magnetization is not None else 0.0,
+                "device_type": self.device_type, "episode_history": self.episode_history.copy()}
+
+    # -- rendering (spin_torque_env.py:556-684): host-side matplotlib, optional --------------------------------
+    def render(self, mode: Optional[str] = None):
+        mode = self.render_mode if mode is None else mode
+        if mode is None:
+            return None
+        if mode not in ("human", "rgb_array"):
+            raise ValueError(f"Unsupported render mode: {mode}")
+        try:
+            import matplotlib
+            matplotlib.use("Agg", force=False)
+            import matplotlib.pyplot as plt
+        except ImportError:
+            warnings.warn("Matplotlib not available, rendering disabled")
+            return None
+        fig, ax = plt.subplots(figsize=(8, 6))
+        m, t = self.current_magnetization, self.target_magnetization
+        ax.quiver(0, 0, m[0], m[1], color="red", scale=1, label="Current")
+        ax.quiver(0, 0, t[0], t[1], color="blue", scale=1, label="Target")
+        ax.add_patch(plt.Circle((0, 0), 1, fill=False, color="gray", alpha=0.5))
+        ax.set_xlim([-1.5, 1.5])
+        ax.set_ylim([-1.5, 1.5])
+        ax.set_aspect("equal")
+        ax.legend()
+        ax.set_title(f"Step {self.step_count}: Alignment = {float(np.dot(m, t)):.3f}")
+        fig.canvas.draw()
+        rgb = np.asarray(fig.canvas.buffer_rgba())[..., :3].copy()
+        plt.close(fig)
+        return rgb if mode == "rgb_array" else None
+
+    def close(self):
+        self._vec.close()
+
+    # -- introspection (spin_torque_env.py:699-745) ------------------------------------------------------------
+    def get_device_info(self):
+        return self.device.get_device_info()
+
+    def get_solver_info(self):
+        return {"method": self.solver_name, "solve_count": self._solve_count, "timeout_count": 0,
+                "last_solve_time": 0.0, "timeout_rate": 0.0, "avg_solve_time": 0.0, "backend": "hip/gfx950"}
+
+    def get_performance_stats(self):
+        return {"profiler": {}, "optimizer": {}, "solver": self.get_solver_info(), "health": {}}
+
+    def analyze_episode(self):
+        if not self.episode_history:
+            return {}
+        h = self.episode_history
+        total_energy = sum(x["energy"] for x in h)
+        final_alignment = h[-1]["alignment"]
+        switching_step = next((i + 1 for i, x in enumerate(h) if x["alignment"] >= self.success_threshold), None)
+        return {"episode_length": len(h), "total_energy": total_energy, "final_alignment": final_alignment,
+                "success": final_alignment >= self.success_threshold, "switching_step": switching_step,
+                "average_reward": float(np.mean([x["reward"] for x in h])),
+                "energy_efficiency": final_alignment / total_energy if total_energy > 0 else 0, "history": h.copy()}
+
+
+def _parse_action_host(a: np.ndarray, max_current: float, max_duration: float):
+    """Host restatement of the action clamp for the `info` dict only (monitoring.py:304-313,
+    spin_torque_env.py:417-431); the values that drive the physics are computed in the kernel."""
+    a = a.copy()
+    if not np.isnan(a[0]):
+        a[0] = np.clip(a[0], -1e8, 1e8)
+    if not np.isnan(a[1]):
+        a[1] = np.clip(a[1], 1e-12, 1e-6)
+    if np.any(np.isnan(a)) or np.any(np.isinf(a)):
+        a = np.array([0.0, 1e-12], dtype=a.dtype)
+    J = float(np.clip(float(a[0]), -max_current, max_current))
+    T = float(np.clip(float(a[1]), 1e-12, max_duration))
+    return J, T
+
+
+def register_envs():
+    """Registers 'SpinTorque-v0' with Gymnasium when it is installed (reference: spin_torque_gym/__init__.py:14-18,
+    envs/__init__.py:14-19; the second registration, max_episode_steps=100, is the one that sticks)."""
+    if _gym is None:
+        return False
+    from gymnasium.envs.registration import register, registry
+    if "SpinTorque-v0" not in registry:
+        register(id="SpinTorque-v0", entry_point="spin_torque_gym_amd.envs:SpinTorqueEnv", max_episode_steps=100,
+                 kwargs={"device_type": "stt_mram"})
+    return True

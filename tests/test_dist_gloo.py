@@ -1,0 +1,97 @@
+"""N > 1 path on CPU: world_size-2 over gloo.  The sharding, the global-index Philox keying and the single
+(obs, reward, done) all-gather are the product's code (spin_torque_gym_amd/distributed.py); the per-rank compute is
+the oracle, injected through the backend test seam (there is no GPU here)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import stt_default_params
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, steps, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    for p in (root, os.path.join(root, "spin-torque-rl-gym_amd"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from helpers import OracleBackend
+    from spin_torque_gym_amd.distributed import ShardedSpinTorqueVecEnv
+    m0, tgt, acts = _inputs(n, steps)
+    env = ShardedSpinTorqueVecEnv(n, device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=True,
+                                  seed=77, backend=OracleBackend)
+    obs, _ = env.reset(options={"initial_state": m0, "target_state": tgt})
+    rec = [obs.clone()]
+    for k in range(steps):
+        obs, r, te, tr, _ = env.step(torch.from_numpy(acts[k]))
+        rec.append((obs.clone(), r.clone(), te.clone(), tr.clone()))
+    assert (env.lo, env.hi) == (rank * n // world, (rank + 1) * n // world)
+    if rank == 0:
+        q.put(rec)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _inputs(n, steps):
+    rng = np.random.default_rng(5)
+    v = rng.normal(0, 1, (n, 3))
+    m0 = v / np.linalg.norm(v, axis=1, keepdims=True)
+    tgt = np.where(rng.integers(0, 2, (n, 1)) == 0, 1.0, -1.0) * np.array([[0.0, 0.0, 1.0]])
+    acts = np.empty((steps, n, 2), dtype=np.float32)
+    acts[..., 0] = rng.uniform(-2e6, 2e6, (steps, n))
+    acts[..., 1] = rng.uniform(1e-10, 3e-10, (steps, n))
+    return m0, tgt, acts
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_env_equals_single_process(oracle_mod):
+    import spin_torque_gym_amd as stg
+    from helpers import OracleBackend
+    n, steps, world = 48, 2, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    rec = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process run over all n envs
+    m0, tgt, acts = _inputs(n, steps)
+    env = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=True,
+                               seed=77, backend=OracleBackend)
+    obs, _ = env.reset(options={"initial_state": m0, "target_state": tgt})
+    assert torch.equal(rec[0], obs)
+    for k in range(steps):
+        obs, r, te, tr, _ = env.step(torch.from_numpy(acts[k]))
+        o2, r2, te2, tr2 = rec[k + 1]
+        # bit-identical: the thermal stream is keyed by the global env index, not by the rank-local one
+        assert torch.equal(o2, obs) and torch.equal(r2, r) and torch.equal(te2, te) and torch.equal(tr2, tr)
+
+
+def test_shard_range_partitions():
+    from spin_torque_gym_amd.distributed import shard_range
+    for n, w in ((1048576, 8), (10, 3), (7, 8)):
+        spans = [shard_range(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,397 @@
+"""Parity tests proper: the HIP path, called through the C-ABI, against (a) the golden vectors recorded from the
+Python reference and (b) the CPU oracle on seeded random batches.  Need a real MI355X: `pytest -m gpu`.
+
+Tolerances.  north_star: m(t) within 1e-5 relative of the CPU reference on identical inputs (thermal off).  The
+assertions below are tighter, at the level actually achieved: the kernels use FMA contraction and the device's
+division/sqrt/pow, so they differ from NumPy by rounding only.
+  RK4 final m ............ <= 1e-10 absolute (unit vectors, up to 5000 sub-steps)
+  RK45 trajectories ...... <= 1e-8 absolute, identical accepted-point counts on the golden cases
+  obs (fp32) ............. <= 2 ulp of fp32 relative + 1e-12
+  reward (fp64) .......... <= 1e-10 relative
+  integer/boolean outputs  exact (sub-step counts, success flags, terminated/truncated, status)
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import sot_default_params, stt_default_params, vcma_default_params
+
+pytestmark = pytest.mark.gpu
+
+TOL_RK4 = 1e-10
+TOL_RK45 = 1e-8
+
+
+@pytest.fixture(scope="module")
+def stg():
+    import spin_torque_gym_amd as s
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    return s
+
+
+def _backend(stg, n, table, cls=None, **cfg):
+    from spin_torque_gym_amd.backend import EnvConfig, HipBackend
+    b = HipBackend(n, EnvConfig(**cfg))
+    b.set_params(table, cls)
+    return b
+
+
+def _flat(stg, d, dev="stt_mram"):
+    return stg.flatten_params(stg.DeviceFactory().create_device(dev, d))
+
+
+# ------------------------------------------------------------------------------------------------
+# solver level vs golden vectors
+# ------------------------------------------------------------------------------------------------
+def test_rk4_solver_vs_golden_g1_g2_g3(stg, golden):
+    g1, g2, g3 = golden("G1_simple_rk4_relax"), golden("G2_simple_rk4_stt"), golden("G3_simple_degenerate")
+    table = [_flat(stg, stt_default_params()), _flat(stg, stt_default_params(volume=8.75e-11)),
+             _flat(stg, stt_default_params(volume=2e-11))]
+    m0, J, T, cls, ref_m, ref_ok, ref_n = [], [], [], [], [], [], []
+    for k in range(len(g1["T"])):
+        m0.append(g1["m0"][g1["m0_index"][k]]); J.append(0.0); T.append(g1["T"][k]); cls.append(0)
+        ref_m.append(g1["m_final"][k]); ref_ok.append(g1["success"][k]); ref_n.append(g1["n_steps"][k])
+    for k in range(len(g2["T"])):
+        m0.append(g2["m0"][g2["m0_index"][k]]); J.append(g2["J"][k]); T.append(g2["T"][k])
+        cls.append(1 if g2["volume"][k] > 5e-11 else 2)
+        ref_m.append(g2["m_final"][k]); ref_ok.append(g2["success"][k]); ref_n.append(g2["n_steps"][k])
+    n_g3 = len(g3["J"])
+    for k in range(n_g3):
+        m0.append(g3["m0"][g3["m0_index"][k]]); J.append(g3["J"][k]); T.append(g3["T"][k]); cls.append(0)
+        ref_m.append(g3["robust_m_last"][k]); ref_ok.append(g3["success"][k]); ref_n.append(-1)
+    n = len(T)
+    b = _backend(stg, n, table, torch.tensor(cls, dtype=torch.uint8), solver="rk4", include_thermal_fluctuations=False)
+    out = b.solve(torch.tensor(np.array(m0).T.copy()), torch.tensor(J), torch.tensor(T))
+    mf = out["m_final"].cpu().numpy().T
+    ok = out["success"].cpu().numpy().astype(bool)
+    npts = out["n_points"].cpu().numpy()
+    ref_ok = np.array(ref_ok, dtype=bool)
+    assert np.array_equal(ok, ref_ok), np.nonzero(ok != ref_ok)
+    ref_n = np.array(ref_n)
+    sel = ref_n >= 0
+    assert np.array_equal(npts[sel], ref_n[sel])                     # H5
+    err = np.abs(mf - np.array(ref_m))[ok]
+    assert err.max() <= TOL_RK4, err.max()
+    assert (~ok).sum() > 50                                          # the degenerate fixture is exercised (H3)
+    # failed solves hand back the initial state (fallback result)
+    assert np.array_equal(mf[~ok], np.array(m0)[~ok])
+    b.close()
+
+
+def test_rk4_trajectory_vs_golden(stg, golden):
+    g1, g2 = golden("G1_simple_rk4_relax"), golden("G2_simple_rk4_stt")
+    table = [_flat(stg, stt_default_params()), _flat(stg, stt_default_params(volume=float(g2["traj_volume"])))]
+    m0 = np.array([g1["m0"][0], g1["m0"][29], g2["m0"][int(g2["traj_m0_index"])]]).T.copy()
+    J = [0.0, 0.0, float(g2["traj_J"])]
+    T = [1e-9, float(np.float32(3.3e-10)), float(g2["traj_T"])]
+    b = _backend(stg, 3, table, torch.tensor([0, 0, 1], dtype=torch.uint8), solver="rk4", include_thermal_fluctuations=False)
+    out = b.solve(torch.tensor(m0), torch.tensor(J), torch.tensor(T), traj_cap=1002)
+    m = out["m"].cpu().numpy()       # [cap,3,N]
+    t = out["t"].cpu().numpy()
+    for lane, (rm, rt) in enumerate(((g1["traj0_m"], g1["traj0_t"]), (g1["traj1_m"], g1["traj1_t"]), (g2["traj_m"], g2["traj_t"]))):
+        k = len(rt)
+        assert int(out["n_points"][lane]) == k - 1
+        assert np.abs(m[:k, :, lane] - rm).max() <= TOL_RK4
+        assert np.abs(t[:k, lane] - rt).max() <= 1e-15 * rt[-1] + 1e-30
+    b.close()
+
+
+@pytest.mark.parametrize("name,vols", [("G4_llgs_rk45_relax", {0: None}), ("G5_llgs_rk45_stt", {0: 9.7e-6, 1: 2e-6})])
+def test_rk45_solver_vs_golden(stg, golden, name, vols):
+    g = golden(name)
+    cases = g["cases"]
+    tags = sorted(vols)
+    table = [_flat(stg, stt_default_params() if vols[t] is None else stt_default_params(volume=vols[t])) for t in tags]
+    n = len(cases)
+    cls = torch.tensor([tags.index(int(c[5])) for c in cases], dtype=torch.uint8)
+    if len(table) == 1:
+        cls = None
+    b = _backend(stg, n, table, cls, solver="rk45", include_thermal_fluctuations=False)
+    cap = max(len(g[f"t_{k}"]) for k in range(n)) + 8
+    out = b.solve(torch.tensor(cases[:, :3].T.copy()), torch.tensor(cases[:, 4].copy()), torch.tensor(cases[:, 3].copy()),
+                  traj_cap=cap, want_energy=True)
+    t, m, e = out["t"].cpu().numpy(), out["m"].cpu().numpy(), out["energy"].cpu().numpy()
+    for k in range(n):
+        rt, rm, re = g[f"t_{k}"], g[f"m_{k}"], g[f"energy_{k}"]
+        assert bool(out["success"][k]) == bool(cases[k, 6])
+        assert int(out["n_points"][k]) == len(rt) - 1, (k, int(out["n_points"][k]), len(rt) - 1)
+        kk = len(rt)
+        assert np.abs(t[:kk, k] - rt).max() <= 1e-9 * rt[-1]
+        assert np.abs(m[:kk, :, k] - rm).max() <= TOL_RK45
+        assert np.abs(e[:kk, k] - re).max() <= 1e-8 * np.abs(re).max()
+        assert np.abs(out["m_final"][:, k].cpu().numpy() - rm[-1]).max() <= TOL_RK45
+    b.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# env level vs golden episodes (through the drop-in SpinTorqueEnv facade, N = 1)
+# ------------------------------------------------------------------------------------------------
+def _episode_setup(tag):
+    from test_oracle_golden import EPISODE_CFG, _episode_params
+    dev, d = _episode_params(tag)
+    return dev, d, EPISODE_CFG.get(tag, {})
+
+
+def test_env_episodes_vs_golden_g6(stg, golden):
+    g = golden("G6_env_episode")
+    for k, tag in enumerate(g["episode_tags"]):
+        tag = str(tag)
+        dev, d, kw = _episode_setup(tag)
+        env = stg.SpinTorqueEnv(device_type=dev, device_params=d, include_thermal_fluctuations=False, **kw)
+        obs0, info0 = env.reset(seed=0, options={"initial_state": g[f"ep{k}_m0"], "target_state": g[f"ep{k}_target"]})
+        assert np.allclose(obs0, g[f"ep{k}_obs"][0], rtol=2e-7, atol=1e-12), tag
+        for j, a in enumerate(g[f"ep{k}_actions"]):
+            obs, r, te, tr, info = env.step(np.array(a, dtype=np.float32))
+            assert np.allclose(obs, g[f"ep{k}_obs"][j + 1], rtol=2e-7, atol=1e-12), (tag, j, obs, g[f"ep{k}_obs"][j + 1])
+            rr = g[f"ep{k}_reward"][j]
+            assert abs(r - rr) <= 1e-10 * max(1.0, abs(rr)), (tag, j, r, rr)
+            assert te == bool(g[f"ep{k}_terminated"][j]) and tr == bool(g[f"ep{k}_truncated"][j]), (tag, j)
+            assert info["simulation_success"] == bool(g[f"ep{k}_success"][j]), (tag, j)
+            re_ = g[f"ep{k}_energy"][j]
+            assert abs(info["energy_consumed"] - re_) <= 1e-12 * max(abs(re_), 1e-300), (tag, j)
+            assert np.abs(env.current_magnetization - g[f"ep{k}_m"][j + 1]).max() <= TOL_RK4, (tag, j)
+            assert abs(env.total_energy - g[f"ep{k}_total_energy"][j]) <= 1e-12 * max(abs(g[f"ep{k}_total_energy"][j]), 1e-300)
+        env.close()
+
+
+def test_reset_seed_parity_g9(stg, golden):
+    """reset(seed=s) reproduces the reference's PCG64 draws (tests/integration/test_environment.py:77-93)."""
+    g = golden("G9_reset_seeds")
+    env = stg.SpinTorqueEnv(include_thermal_fluctuations=False)
+    for s in range(64):
+        obs, _ = env.reset(seed=s)
+        assert np.abs(env.current_magnetization - g["state"][s, :3]).max() <= 1e-15
+        assert np.array_equal(env.target_magnetization, g["state"][s, 3:])
+        assert np.allclose(obs, g["obs"][s], rtol=2e-7, atol=0)
+    env.reset(seed=1234)
+    for row in g["continued_from_1234"]:
+        env.reset()
+        assert np.abs(env.current_magnetization - row[:3]).max() <= 1e-15
+        assert np.array_equal(env.target_magnetization, row[3:])
+    env.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# batched env vs the oracle on seeded random inputs (same host code, two backends)
+# ------------------------------------------------------------------------------------------------
+def _run_pair(stg, n, steps, actions_fn, seed=0, **kw):
+    from helpers import OracleBackend, unit_rows
+    rng = np.random.default_rng(seed)
+    m0 = unit_rows(rng, n)
+    tgt = np.where(rng.integers(0, 2, (n, 1)) == 0, 1.0, -1.0) * np.array([[0.0, 0.0, 1.0]])
+    envs = [stg.SpinTorqueVecEnv(n, **kw), stg.SpinTorqueVecEnv(n, backend=OracleBackend, **kw)]
+    outs = []
+    for env in envs:
+        o, _ = env.reset(options={"initial_state": m0, "target_state": tgt})
+        rec = [dict(obs=o.cpu().numpy().copy())]
+        arng = np.random.default_rng(seed + 1)
+        for s in range(steps):
+            a = actions_fn(arng, n, s)
+            o, r, te, tr, info = env.step(torch.from_numpy(a))
+            rec.append(dict(obs=o.cpu().numpy().copy(), reward=info["reward_f64"].cpu().numpy().copy(),
+                            term=te.cpu().numpy().copy(), trunc=tr.cpu().numpy().copy(),
+                            status=info["status"].cpu().numpy().copy(), energy=info["energy"].cpu().numpy().copy(),
+                            m=env.get_state()["m"].cpu().numpy().copy()))
+        outs.append(rec)
+        env.close()
+    return outs
+
+
+def _compare(outs, tol_m, obs_rtol=3e-7):
+    hip, ora = outs
+    worst = 0.0
+    assert np.allclose(hip[0]["obs"], ora[0]["obs"], rtol=obs_rtol, atol=1e-12)
+    for s in range(1, len(hip)):
+        h, o = hip[s], ora[s]
+        assert np.array_equal(h["status"], o["status"]), (s, np.nonzero(h["status"] != o["status"]))
+        assert np.array_equal(h["term"], o["term"]) and np.array_equal(h["trunc"], o["trunc"]), s
+        worst = max(worst, np.abs(h["m"] - o["m"]).max())
+        assert np.abs(h["m"] - o["m"]).max() <= tol_m, (s, np.abs(h["m"] - o["m"]).max())
+        assert np.allclose(h["obs"], o["obs"], rtol=obs_rtol, atol=max(1e-12, 10 * tol_m)), s
+        assert np.allclose(h["reward"], o["reward"], rtol=1e-10, atol=max(1e-12, 10 * tol_m)), s
+        assert np.allclose(h["energy"], o["energy"], rtol=1e-12, atol=0), s
+    return worst
+
+
+def _uniform_actions(jmax, tlo, thi):
+    def fn(rng, n, s):
+        a = np.empty((n, 2), dtype=np.float32)
+        a[:, 0] = rng.uniform(-jmax, jmax, n)
+        a[:, 1] = rng.uniform(tlo, thi, n)
+        return a
+    return fn
+
+
+def test_cfg2_rk4_4096_envs_vs_oracle(stg):
+    """BASELINE config 2 shape: 4096 STT-MRAM envs, T = 0 K (thermal off), well-conditioned volume, random pulses."""
+    outs = _run_pair(stg, 4096, 3, _uniform_actions(2e6, 1e-10, 1e-9), device_params=stt_default_params(volume=8.75e-11),
+                     include_thermal_fluctuations=False, solver="rk4", seed=3)
+    worst = _compare(outs, TOL_RK4)
+    print("cfg2 rk4 worst |dm| =", worst)
+    # the batch does switch some envs and finishes some episodes
+    assert outs[0][-1]["term"].sum() > 0
+
+
+def test_cfg2_rk45_1024_envs_vs_oracle(stg):
+    outs = _run_pair(stg, 1024, 2, _uniform_actions(2e6, 1e-10, 6e-10), device_params=stt_default_params(volume=9.7e-6),
+                     include_thermal_fluctuations=False, solver="rk45", seed=4)
+    worst = _compare(outs, TOL_RK45)
+    print("cfg2 rk45 worst |dm| =", worst)
+
+
+def test_default_params_noop_regime_vs_oracle(stg):
+    """Default STT parameters with random non-zero currents: almost every step is the H3 no-op; exact status parity."""
+    outs = _run_pair(stg, 512, 2, _uniform_actions(2e6, 1e-10, 5e-10), include_thermal_fluctuations=False, solver="rk4", seed=5)
+    _compare(outs, TOL_RK4)
+    st = outs[0][1]["status"]
+    assert (st == 1).mean() > 0.9
+
+
+def test_thermal_on_same_philox_stream_vs_oracle(stg):
+    """Thermal on (config 3 shape, reduced N): kernel and oracle key the same Philox stream, so trajectories agree to
+    rounding plus the fp32 transcendental differences in the normals (~1e-6 relative on a 1e-9-relative field)."""
+    outs = _run_pair(stg, 2048, 2, _uniform_actions(2e6, 1e-10, 4e-10), device_params=stt_default_params(volume=8.75e-11),
+                     include_thermal_fluctuations=True, temperature=300.0, solver="rk4", seed=1234)
+    _compare(outs, 1e-9)
+
+
+def test_mixed_device_classes_vs_oracle(stg):
+    """Config 4 shape (reduced N): STT/SOT/VCMA classes in one batch, per-class constants from LDS."""
+    n = 3072
+    cls = (np.arange(n) % 3).astype(np.uint8)
+    types = ["stt_mram", "sot_mram", "vcma_mram"]
+    params = [stt_default_params(volume=8.75e-11), sot_default_params(polarization=0.7, volume=8.75e-11),
+              vcma_default_params(polarization=0.6, volume=5e-11, easy_axis=np.array([0.1, 0.0, 1.0]),
+                                  reference_magnetization=np.array([0.0, 0.2, 1.0]))]
+    outs = _run_pair(stg, n, 2, _uniform_actions(2e6, 1e-10, 5e-10), device_type=types, device_params=params,
+                     class_index=cls, include_thermal_fluctuations=False, solver="rk4", seed=6)
+    _compare(outs, TOL_RK4)
+
+
+def test_bad_actions_and_truncation_vs_oracle(stg):
+    def fn(rng, n, s):
+        a = np.empty((n, 2), dtype=np.float32)
+        a[:, 0] = rng.uniform(-3e6, 3e6, n)
+        a[:, 1] = rng.uniform(-1e-9, 8e-10, n)
+        a[::7, 0] = np.nan
+        a[3::11, 1] = np.inf
+        a[5::13, 0] = -np.inf
+        return a
+    outs = _run_pair(stg, 640, 4, fn, device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=False,
+                     solver="rk4", max_steps=3, seed=7)
+    _compare(outs, TOL_RK4)
+    assert outs[0][3]["trunc"].all()
+
+
+# ------------------------------------------------------------------------------------------------
+# thermal field distribution (the reference's own moment test) and size-independent properties at full size
+# ------------------------------------------------------------------------------------------------
+def test_thermal_normals_moments_and_oracle_stream(stg, oracle_mod):
+    b = _backend(stg, 4096, [_flat(stg, stt_default_params())], solver="rk4", seed=1234)
+    z = b.thermal_normals(env_step=5, call0=0, n_calls=16).cpu().numpy()       # [16,3,4096]
+    flat = z.transpose(1, 0, 2).reshape(3, -1)
+    n = flat.shape[1]
+    assert np.all(np.abs(flat.mean(axis=1)) < 5 / np.sqrt(n))
+    assert np.all(np.abs(flat.std(axis=1) - 1.0) < 5 / np.sqrt(2 * n))
+    # reference's tolerance on 1000 draws (tests/test_comprehensive_suite.py:447-476)
+    sub = flat[:, :1000]
+    assert np.all(np.abs(sub.mean(axis=1)) < 0.1) and np.all(np.abs(sub.std(axis=1) - 1) < 0.2)
+    # kurtosis and cross-correlation sanity
+    assert np.all(np.abs((flat ** 4).mean(axis=1) - 3.0) < 0.15)
+    assert abs(np.corrcoef(flat)[0, 1]) < 0.01 and abs(np.corrcoef(flat)[0, 2]) < 0.01
+    # same stream as the oracle (Philox4x32-10 + Box-Muller), up to fp32 transcendental rounding
+    for env in (0, 1, 77, 4095):
+        for call in (0, 3, 15):
+            ref = oracle_mod.thermal_normals(1234, env, 5, call)
+            assert np.abs(z[call, :, env] - ref).max() < 2e-5
+    # strengths equal the reference's formulas (G8) through the library's host code
+    assert np.isclose(b.thermal_strength(0), oracle_mod.thermal_strength(oracle_mod.make_params(stt_default_params()), 2.21e5, 300.0, 0), rtol=1e-15)
+    b.close()
+
+
+def test_full_size_properties_65536(stg):
+    """Config 3 size: 65 536 envs, thermal on.  Size-independent properties: |m| = 1, finite outputs, determinism
+    (same seed -> identical bits), partition invariance (two half-size contexts with env_id0 offsets = one full one)."""
+    from spin_torque_gym_amd.backend import EnvConfig, HipBackend
+    n = 65536
+    rng = np.random.default_rng(11)
+    v = rng.normal(0, 1, (3, n)); m0 = torch.tensor(v / np.linalg.norm(v, axis=0))
+    tgt = torch.zeros((3, n), dtype=torch.float64); tgt[2] = torch.tensor(np.where(rng.integers(0, 2, n) == 0, 1.0, -1.0))
+    act = torch.empty((2, n), dtype=torch.float32)
+    act[0] = torch.tensor(rng.uniform(-2e6, 2e6, n), dtype=torch.float32)
+    act[1] = torch.tensor(rng.uniform(1e-10, 3e-10, n), dtype=torch.float32)
+    table = [_flat(stg, stt_default_params(volume=8.75e-11))]
+    cfg = EnvConfig(solver="rk4", include_thermal_fluctuations=True, seed=99)
+
+    def run(n_sub, off):
+        b = HipBackend(n_sub, cfg, env_id0=off)
+        b.set_params(table)
+        b.reset(None, m0[:, off:off + n_sub], tgt[:, off:off + n_sub], 1)
+        res = [t.clone() for t in b.step(act[:, off:off + n_sub])]
+        m = b.get_state()["m"].clone()
+        b.close()
+        return res, m
+    full, m_full = run(n, 0)
+    again, m_again = run(n, 0)
+    lo, m_lo = run(n // 2, 0)
+    hi, m_hi = run(n // 2, n // 2)
+    assert torch.equal(m_full, m_again) and all(torch.equal(a, b) for a, b in zip(full, again))
+    assert torch.equal(m_full, torch.cat([m_lo, m_hi], dim=1))
+    assert torch.equal(full[0], torch.cat([lo[0], hi[0]], dim=1))
+    norm = torch.linalg.norm(m_full, dim=0)
+    assert torch.all(torch.abs(norm - 1) < 1e-14)
+    assert torch.isfinite(full[0]).all() and torch.isfinite(full[2]).all()
+
+
+def test_skip_done_and_autoreset(stg):
+    n = 256
+    env = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=False,
+                               max_steps=2, skip_done=True, seed=5)
+    env.reset(seed=1)
+    a = torch.zeros((n, 2), dtype=torch.float32); a[:, 1] = 1e-10
+    env.step(a); env.step(a)
+    m_before = env.get_state()["m"].clone()
+    _, _, _, tr, info = env.step(a)                       # every env is truncated by now: inactive, state frozen
+    assert tr.all() and (info["status"] == 3).all()
+    assert torch.equal(env.get_state()["m"], m_before)
+    env.close()
+    env = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=False,
+                               max_steps=2, autoreset=True, seed=5)
+    env.reset(seed=1)
+    for _ in range(5):
+        obs, r, te, tr, info = env.step(a)
+    st = env.get_state()
+    assert int(st["step_count"].max()) <= 2 and torch.all(torch.abs(torch.linalg.norm(st["m"], dim=0) - 1) < 1e-14)
+    env.close()
+
+
+def test_step_many_equals_repeated_step(stg):
+    n, K = 512, 4
+    rng = np.random.default_rng(2)
+    acts = np.stack([_uniform_actions(2e6, 1e-10, 3e-10)(rng, n, s) for s in range(K)])     # [K,N,2]
+    kw = dict(device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=True, seed=8)
+    e1 = stg.SpinTorqueVecEnv(n, **kw); e1.reset(seed=3)
+    e2 = stg.SpinTorqueVecEnv(n, **kw); e2.reset(seed=3)
+    obs_k = []
+    for k in range(K):
+        o, r, te, tr, info = e1.step(torch.from_numpy(acts[k]))
+        obs_k.append((o.clone(), info["reward_f64"].clone(), te.clone(), tr.clone()))
+    om, rm, tem, trm, infom = e2.step_many(torch.from_numpy(acts))
+    for k in range(K):
+        assert torch.equal(om[k], obs_k[k][0]) and torch.equal(infom["reward_f64"][k], obs_k[k][1])
+        assert torch.equal(tem[k], obs_k[k][2]) and torch.equal(trm[k], obs_k[k][3])
+    assert torch.equal(e1.get_state()["m"], e2.get_state()["m"])
+    e1.close(); e2.close()
+
+
+def test_state_dict_roundtrip(stg):
+    n = 128
+    kw = dict(device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=True, seed=8)
+    a = torch.from_numpy(_uniform_actions(2e6, 1e-10, 3e-10)(np.random.default_rng(0), n, 0))
+    e1 = stg.SpinTorqueVecEnv(n, **kw); e1.reset(seed=3); e1.step(a)
+    sd = e1.state_dict()
+    o1, r1, *_ = e1.step(a)
+    e2 = stg.SpinTorqueVecEnv(n, **kw); e2.load_state_dict(sd)
+    o2, r2, *_ = e2.step(a)
+    assert torch.equal(o1, o2) and torch.equal(r1, r2)
+    e1.close(); e2.close()
