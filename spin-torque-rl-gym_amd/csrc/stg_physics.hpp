@@ -15,8 +15,9 @@
 //
 // Floating point: IEEE fp64, denormals on, no fast-math.  FMA contraction is allowed in the RHS
 // algebra (it only changes roundings at the 1e-16 level; parity bound is 1e-5, measured ~1e-12) but
-// NOT where the reference's branch decisions hang on an exact rounding: sub-step times
-// use __dmul_rn/__dadd_rn.
+// NOT where the reference's branch decisions hang on an exact rounding: sub-step and stage times (SURVEY
+// H4/H5) go through mul_x/add_x/sub_x below, which are compiled with contraction off (ROCm's __dadd_rn/__dmul_rn are
+// plain operators and DO get fused; the build uses -ffp-contract=fast-honor-pragmas so the pragma holds).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -57,6 +58,23 @@ enum ClassConst : int {
 struct V3 {
     double x, y, z;
 };
+
+// single IEEE operations that must never be contracted into an FMA with a neighbour
+__device__ __forceinline__ double mul_x(double a, double b) {
+#pragma clang fp contract(off)
+    const double r = a * b;
+    return r;
+}
+__device__ __forceinline__ double add_x(double a, double b) {
+#pragma clang fp contract(off)
+    const double r = a + b;
+    return r;
+}
+__device__ __forceinline__ double sub_x(double a, double b) {
+#pragma clang fp contract(off)
+    const double r = a - b;
+    return r;
+}
 
 __device__ __forceinline__ V3 cross(const V3& a, const V3& b) {
     return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
@@ -181,10 +199,10 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
     bool zr;
     int resets = simple_validate(m, zr);                                   // simple_solver.py:119
     // simple_solver.py:137-139, in exactly these roundings
-    double dt = fmin(max_step, __ddiv_rn(T, 100.0));
-    int n = (int)__ddiv_rn(T, dt);
+    double dt = fmin(max_step, (T / 100.0));
+    int n = (int)(T / dt);
     n = n < 10 ? 10 : n;
-    dt = __ddiv_rn(T, (double)n);
+    dt = T / (double)n;
     o.n = n;
     o.work = n;
     const double half_dt = 0.5 * dt;
@@ -196,9 +214,9 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
     for (int i = 0; i < n; ++i) {
         // t_i = linspace(0, T, n+1)[i] = i*step; stage times t_i + dt/2, t_i + dt; the pulse is on while
         // t <= T (spin_torque_env.py:442-443).  Only the last stages can land 1 ulp beyond T.
-        const double ti = __dmul_rn((double)i, dt);
-        const double a2 = (__dadd_rn(ti, __dmul_rn(dt, 0.5)) <= T) ? aJ : 0.0;
-        const double a4 = (__dadd_rn(ti, dt) <= T) ? aJ : 0.0;
+        const double ti = mul_x((double)i, dt);
+        const double a2 = (add_x(ti, mul_x(dt, 0.5)) <= T) ? aJ : 0.0;
+        const double a4 = (add_x(ti, dt) <= T) ? aJ : 0.0;
         V3 mn;
         if (METHOD == 1) {
             const V3 h0 = THERMAL ? thermal_normals(rk.seed, rk.env_id, rk.env_step, 4u * i) : zero;
@@ -228,7 +246,7 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
         resets += simple_validate(mn, zr);                                 // simple_solver.py:168
         fail |= zr;                                                        // robust_solver.py:192-205
         m = mn;
-        if (RECORD) rec.put(i + 1, (i + 1 == n) ? T : __dmul_rn((double)(i + 1), dt), m, 0.0);
+        if (RECORD) rec.put(i + 1, (i + 1 == n) ? T : mul_x((double)(i + 1), dt), m, 0.0);
     }
     o.resets = resets;
     if (fail) return o;
@@ -318,7 +336,7 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
         double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
         h0 = fmin(h0, T);
         const V3 y1{y.x + h0 * f.x, y.y + h0 * f.y, y.z + h0 * f.z};
-        const V3 f1 = fun(__dadd_rn(t, h0), y1);
+        const V3 f1 = fun(add_x(t, h0), y1);
         const double d2 = rms3(V3{(f1.x - f.x) / sc.x, (f1.y - f.y) / sc.y, (f1.z - f.z) / sc.z}) / h0;
         const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : pow(0.01 / fmax(d1, d2), 0.2);
         h_abs = fmin(fmin(100.0 * h0, h1), fmin(T, max_step));
@@ -335,31 +353,31 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
         while (!accepted) {
             if (h_abs < min_step || attempts >= max_attempts) { ok = false; break; }
             ++attempts;
-            t_new = __dadd_rn(t, h_abs);
+            t_new = add_x(t, h_abs);
             if (t_new - T > 0.0) t_new = T;
-            const double h = __dsub_rn(t_new, t);
+            const double h = sub_x(t_new, t);
             h_abs = fabs(h);
             // rk_step (rk.py:14-70); stage times must not be contracted into FMAs (they gate the pulse)
             const V3 k1 = f;
-            const V3 k2 = fun(__dadd_rn(t, __dmul_rn(C2, h)), V3{y.x + (k1.x * A21) * h, y.y + (k1.y * A21) * h, y.z + (k1.z * A21) * h});
-            const V3 k3 = fun(__dadd_rn(t, __dmul_rn(C3, h)),
+            const V3 k2 = fun(add_x(t, mul_x(C2, h)), V3{y.x + (k1.x * A21) * h, y.y + (k1.y * A21) * h, y.z + (k1.z * A21) * h});
+            const V3 k3 = fun(add_x(t, mul_x(C3, h)),
                               V3{y.x + (k1.x * A31 + k2.x * A32) * h, y.y + (k1.y * A31 + k2.y * A32) * h,
                                  y.z + (k1.z * A31 + k2.z * A32) * h});
-            const V3 k4 = fun(__dadd_rn(t, __dmul_rn(C4, h)),
+            const V3 k4 = fun(add_x(t, mul_x(C4, h)),
                               V3{y.x + (k1.x * A41 + k2.x * A42 + k3.x * A43) * h, y.y + (k1.y * A41 + k2.y * A42 + k3.y * A43) * h,
                                  y.z + (k1.z * A41 + k2.z * A42 + k3.z * A43) * h});
-            const V3 k5 = fun(__dadd_rn(t, __dmul_rn(C5, h)),
+            const V3 k5 = fun(add_x(t, mul_x(C5, h)),
                               V3{y.x + (k1.x * A51 + k2.x * A52 + k3.x * A53 + k4.x * A54) * h,
                                  y.y + (k1.y * A51 + k2.y * A52 + k3.y * A53 + k4.y * A54) * h,
                                  y.z + (k1.z * A51 + k2.z * A52 + k3.z * A53 + k4.z * A54) * h});
-            const V3 k6 = fun(__dadd_rn(t, h),
+            const V3 k6 = fun(add_x(t, h),
                               V3{y.x + (k1.x * A61 + k2.x * A62 + k3.x * A63 + k4.x * A64 + k5.x * A65) * h,
                                  y.y + (k1.y * A61 + k2.y * A62 + k3.y * A63 + k4.y * A64 + k5.y * A65) * h,
                                  y.z + (k1.z * A61 + k2.z * A62 + k3.z * A63 + k4.z * A64 + k5.z * A65) * h});
             y_new = V3{y.x + h * (k1.x * B1 + k3.x * B3 + k4.x * B4 + k5.x * B5 + k6.x * B6),
                        y.y + h * (k1.y * B1 + k3.y * B3 + k4.y * B4 + k5.y * B5 + k6.y * B6),
                        y.z + h * (k1.z * B1 + k3.z * B3 + k4.z * B4 + k5.z * B5 + k6.z * B6)};
-            f_new = fun(__dadd_rn(t, h), y_new);
+            f_new = fun(add_x(t, h), y_new);
             const V3 ev{(k1.x * E1 + k3.x * E3 + k4.x * E4 + k5.x * E5 + k6.x * E6 + f_new.x * E7) * h,
                         (k1.y * E1 + k3.y * E3 + k4.y * E4 + k5.y * E5 + k6.y * E6 + f_new.y * E7) * h,
                         (k1.z * E1 + k3.z * E3 + k4.z * E4 + k5.z * E5 + k6.z * E6 + f_new.z * E7) * h};

@@ -85,7 +85,7 @@ def test_rk4_trajectory_vs_golden(stg, golden):
     J = [0.0, 0.0, float(g2["traj_J"])]
     T = [1e-9, float(np.float32(3.3e-10)), float(g2["traj_T"])]
     b = _backend(stg, 3, table, torch.tensor([0, 0, 1], dtype=torch.uint8), solver="rk4", include_thermal_fluctuations=False)
-    out = b.solve(torch.tensor(m0), torch.tensor(J), torch.tensor(T), traj_cap=1002)
+    out = b.solve(torch.tensor(m0), torch.tensor(J, dtype=torch.float64), torch.tensor(T, dtype=torch.float64), traj_cap=1002)
     m = out["m"].cpu().numpy()       # [cap,3,N]
     t = out["t"].cpu().numpy()
     for lane, (rm, rt) in enumerate(((g1["traj0_m"], g1["traj0_t"]), (g1["traj1_m"], g1["traj1_t"]), (g2["traj_m"], g2["traj_t"]))):
@@ -351,8 +351,8 @@ def test_skip_done_and_autoreset(stg):
     a = torch.zeros((n, 2), dtype=torch.float32); a[:, 1] = 1e-10
     env.step(a); env.step(a)
     m_before = env.get_state()["m"].clone()
-    _, _, _, tr, info = env.step(a)                       # every env is truncated by now: inactive, state frozen
-    assert tr.all() and (info["status"] == 3).all()
+    _, _, te, tr, info = env.step(a)                      # every episode has ended by now: inactive, state frozen
+    assert (te | tr).all() and (info["status"] == 3).all()
     assert torch.equal(env.get_state()["m"], m_before)
     env.close()
     env = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=False,
