@@ -48,20 +48,65 @@ void stgo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t o
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-void stgo_thermal_normals(uint64_t seed, uint64_t env_id, uint32_t env_step, uint32_t call_idx, double z[3]) {
-    uint32_t ctr[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), env_step, call_idx};
+/* Normal stream of one (env, env step): xoshiro128++ seeded by Philox4x32-10(key = seed, counter = (env_id, env_step,
+ * tag)); consecutive outputs -> 24-bit uniforms -> fp32 Box-Muller pairs; RHS call j consumes normals 3j..3j+2 (even
+ * calls draw two pairs and keep the 4th normal for the next, odd, call).  Same construction as the HIP kernels
+ * (csrc/stg_physics.hpp: NormalStream), restated. */
+typedef struct { uint32_t s[4]; float carry; uint32_t calls; } nstream;
+
+static void ns_init(nstream* g, uint64_t seed, uint64_t env_id, uint32_t env_step, uint32_t tag) {
+    uint32_t ctr[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), env_step, tag};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-    uint32_t r[4];
-    stgo_philox4x32_10(ctr, key, r);
-    /* 24-bit uniforms in (0,1), fp32 Box-Muller */
-    const float s = 1.0f / 16777216.0f;
-    float u0 = ((float)(r[0] >> 8) + 0.5f) * s, u1 = ((float)(r[1] >> 8) + 0.5f) * s;
-    float u2 = ((float)(r[2] >> 8) + 0.5f) * s, u3 = ((float)(r[3] >> 8) + 0.5f) * s;
-    float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
+    stgo_philox4x32_10(ctr, key, g->s);
+    g->s[3] |= 1u;
+    g->carry = 0.0f;
+    g->calls = 0;
+}
+static uint32_t ns_next(nstream* g) {
+    uint32_t* s = g->s;
+    uint32_t a = s[0] + s[3];
+    uint32_t result = ((a << 7) | (a >> 25)) + s[0];
+    uint32_t t = s[1] << 9;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t;
+    s[3] = (s[3] << 11) | (s[3] >> 21);
+    return result;
+}
+static void ns_pair(nstream* g, float* a, float* b) {
+    const float sc = 1.0f / 16777216.0f;
+    float u0 = ((float)(ns_next(g) >> 8) + 0.5f) * sc;
+    float u1 = ((float)(ns_next(g) >> 8) + 0.5f) * sc;
+    float r = sqrtf(-2.0f * logf(u0));
     const float two_pi = 6.28318530717958647692f;
-    z[0] = (double)(ra * cosf(two_pi * u1));
-    z[1] = (double)(ra * sinf(two_pi * u1));
-    z[2] = (double)(rb * cosf(two_pi * u3));
+    *a = r * cosf(two_pi * u1);
+    *b = r * sinf(two_pi * u1);
+}
+static void ns_draw3(nstream* g, double z[3]) {
+    float a, b, c, d;
+    if ((g->calls & 1u) == 0) {
+        ns_pair(g, &a, &b);
+        ns_pair(g, &c, &d);
+        g->carry = d;
+        z[0] = a; z[1] = b; z[2] = c;
+    } else {
+        ns_pair(g, &a, &b);
+        z[0] = g->carry; z[1] = a; z[2] = b;
+    }
+    g->calls++;
+}
+
+void stgo_thermal_normals(uint64_t seed, uint64_t env_id, uint32_t env_step, uint32_t call_idx, double z[3]) {
+    nstream g;
+    ns_init(&g, seed, env_id, env_step, 0u);
+    for (uint32_t c = 0; c <= call_idx; ++c) ns_draw3(&g, z);
+}
+
+/* device-side reset draw of the kernels (csrc/spintorque_hip.hip: device_reset_draw), restated */
+void stgo_reset_draw(uint64_t seed, uint64_t env_id, uint32_t rng_step, int n_targets, double z[3], int* target_idx) {
+    nstream g;
+    ns_init(&g, seed ^ 0x9E3779B97F4A7C15ull, env_id, rng_step, 0xFFFFFFFFu);
+    ns_draw3(&g, z);
+    uint32_t r = ns_next(&g);
+    *target_idx = (int)(((uint64_t)r * (uint64_t)n_targets) >> 32);
 }
 
 double stgo_thermal_strength(const stgo_params* p, double gamma, double temperature, int which) {
@@ -159,6 +204,8 @@ int stgo_simple_solve(const double m0[3], double T, const stgo_params* p, const 
     const int thermal = c->thermal && c->temperature > 0;
     const double hs = thermal ? stgo_thermal_strength(p, c->gamma, c->temperature, 0) : 0.0;
     int zero_row = -1;
+    nstream g;
+    if (thermal) ns_init(&g, c->seed, env_id, env_step, 0u);
     if (traj && traj_cap_rows > 0) { traj[0] = m[0]; traj[1] = m[1]; traj[2] = m[2]; }
 
     for (int i = 0; i < n; ++i) {
@@ -173,7 +220,7 @@ int stgo_simple_solve(const double m0[3], double T, const stgo_params* p, const 
             /* spin_torque_env.py:442-443  current_func(t) = J if t <= T else 0 */
             double Jt = (ts <= T) ? J : 0.0;
             if (thermal) {
-                stgo_thermal_normals(c->seed, env_id, env_step, (uint32_t)(4 * i + s), z);
+                ns_draw3(&g, z);
                 hth[0] = hs * z[0]; hth[1] = hs * z[1]; hth[2] = hs * z[2];
             }
             double f[3];
@@ -284,17 +331,16 @@ static const double DP_E[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 172
 
 typedef struct {
     const stgo_params* p; const stgo_config* c; double J, T, hs; int thermal;
-    uint64_t env_id; uint32_t env_step; uint32_t call_idx;
+    nstream g;
 } rhs_ctx;
 
 static void llgs_fun(rhs_ctx* x, double t, const double y[3], double out[3]) {
     double Jt = (t <= x->T) ? x->J : 0.0;           /* spin_torque_env.py:442-443 */
     double hth[3], z[3];
     if (x->thermal) {
-        stgo_thermal_normals(x->c->seed, x->env_id, x->env_step, x->call_idx, z);
+        ns_draw3(&x->g, z);
         hth[0] = x->hs * z[0]; hth[1] = x->hs * z[1]; hth[2] = x->hs * z[2];
     }
-    x->call_idx++;
     stgo_llgs_rhs(y, x->p, x->c->gamma, Jt, x->thermal ? hth : 0, out);
 }
 
@@ -305,8 +351,12 @@ int64_t stgo_llgs_solve(const double m0[3], double T, const stgo_params* p, cons
                         double J, uint64_t env_id, uint32_t env_step,
                         double m_final[3], int32_t* success, int64_t* n_attempts,
                         double* t_out, double* m_out, double* e_out, double* tq_out, int64_t cap) {
-    rhs_ctx x = {p, c, J, T, 0.0, c->thermal ? 1 : 0, env_id, env_step, 0};
-    if (x.thermal) x.hs = stgo_thermal_strength(p, c->gamma, c->temperature, 1);   /* llgs_solver.py:85-90 */
+    rhs_ctx x;
+    x.p = p; x.c = c; x.J = J; x.T = T; x.hs = 0.0; x.thermal = c->thermal ? 1 : 0;
+    if (x.thermal) {
+        x.hs = stgo_thermal_strength(p, c->gamma, c->temperature, 1);               /* llgs_solver.py:85-90 */
+        ns_init(&x.g, c->seed, env_id, env_step, 0u);
+    }
     const double rtol = c->rtol, atol = c->atol, max_step = c->max_step;
     double y[3], f[3];
     double n0 = norm3(m0);                            /* llgs_solver.py:76 */

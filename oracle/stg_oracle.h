@@ -130,10 +130,12 @@ void stgo_env_step_batch(int64_t n, stgo_env_state* s, const float* actions /*[n
                          const stgo_params* params, const uint8_t* cls, const stgo_config* c,
                          uint64_t env_id0, stgo_step_out* out, int n_threads);
 
-/* thermal-field generator shared (by construction, not by code) with the HIP kernels:
- * Philox4x32-10 keyed (seed_lo, seed_hi) with counter (env_id_lo, env_id_hi, env_step, call_idx),
- * two fp32 Box-Muller pairs -> 3 normals.  Used only when thermal is on. */
+/* thermal-field generator, the same construction as the HIP kernels' (restated, not shared code): per (env, env step)
+ * one xoshiro128++ stream seeded by Philox4x32-10(key = seed, counter = (env_id, env_step, tag)), 24-bit uniforms,
+ * fp32 Box-Muller pairs, RHS call j consuming normals 3j..3j+2.  stgo_thermal_normals returns the normals of call
+ * `call_idx` (replaying the stream from call 0). */
 void stgo_thermal_normals(uint64_t seed, uint64_t env_id, uint32_t env_step, uint32_t call_idx, double z[3]);
+void stgo_reset_draw(uint64_t seed, uint64_t env_id, uint32_t rng_step, int n_targets, double z[3], int* target_idx);
 void stgo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
 int stgo_max_threads(void);

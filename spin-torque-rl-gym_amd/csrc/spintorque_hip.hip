@@ -115,20 +115,19 @@ __device__ __forceinline__ SolveOut run_solver(const V3& m, double J, double T, 
 }
 
 // SpinTorqueEnv.reset draws (spin_torque_env.py:286-299) from the device generator: normal(0,1,3) normalised and a
-// uniform choice among the target states.  Counter word 3 = 0xFFFFFFFF/0xFFFFFFFE keeps these draws apart from the
-// thermal field's (whose call index never gets there).
+// uniform choice among the target states, from this env's stream tagged 0xFFFFFFFF (the thermal field uses tag 0).
 __device__ __forceinline__ void device_reset_draw(uint64_t seed, uint64_t env_id, uint32_t rng_step, const CfgView& c,
                                                   bool draw_m, bool draw_t, V3& m, V3& tgt) {
+    NormalStream ns;
+    ns.init(seed ^ 0x9E3779B97F4A7C15ull, env_id, rng_step, 0xFFFFFFFFu);
+    const V3 z = ns.draw3_even();
+    const uint32_t r = ns.next();
     if (draw_m) {
-        V3 z = thermal_normals(seed ^ 0x9E3779B97F4A7C15ull, env_id, rng_step, 0xFFFFFFFFu);
         const double n = sqrt(dot(z, z));
         m = (n < 1e-12) ? V3{0.0, 0.0, 1.0} : V3{z.x / n, z.y / n, z.z / n};
     }
     if (draw_t) {
-        uint32_t r[4];
-        philox4x32_10((uint32_t)env_id, (uint32_t)(env_id >> 32), rng_step, 0xFFFFFFFEu,
-                      (uint32_t)(seed ^ 0x9E3779B97F4A7C15ull), (uint32_t)((seed ^ 0x9E3779B97F4A7C15ull) >> 32), r);
-        const int idx = (int)__umulhi(r[0], (uint32_t)c.n_targets);
+        const int idx = (int)__umulhi(r, (uint32_t)c.n_targets);
         tgt = V3{c.targets[idx][0], c.targets[idx][1], c.targets[idx][2]};
     }
 }
@@ -334,10 +333,14 @@ __global__ void stg_normals_kernel(uint64_t seed, int64_t env_id0, int64_t N, ui
                                    int32_t n_calls, double* z) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    for (int c = 0; c < n_calls; ++c) {
-        const V3 v = thermal_normals(seed, (uint64_t)(env_id0 + i), env_step, call0 + (uint32_t)c);
-        double* b = z + (int64_t)c * 3 * N + i;
-        b[0] = v.x; b[N] = v.y; b[2 * N] = v.z;
+    NormalStream ns;
+    ns.init(seed, (uint64_t)(env_id0 + i), env_step, 0u);
+    for (uint32_t c = 0; c < call0 + (uint32_t)n_calls; ++c) {       // the stream is sequential: replay from call 0
+        const V3 v = (c & 1u) ? ns.draw3_odd() : ns.draw3_even();
+        if (c >= call0) {
+            double* b = z + (int64_t)(c - call0) * 3 * N + i;
+            b[0] = v.x; b[N] = v.y; b[2 * N] = v.z;
+        }
     }
 }
 

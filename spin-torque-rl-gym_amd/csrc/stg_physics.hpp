@@ -76,6 +76,25 @@ __device__ __forceinline__ double sub_x(double a, double b) {
     return r;
 }
 
+// 1/sqrt(s) for s in [1e-24, DBL_MAX]: hardware seed (v_rsq_f64) + one third-order correction, ~1 ulp.
+// Replaces sqrt + three IEEE divisions per normalisation (the reference's m / |m|); the quotient differs from the
+// correctly rounded one by <= 2 ulp per component.  s = +inf gives 0, so a finite vector whose squared norm
+// overflowed still becomes the all-zero row the reference produces.
+__device__ __forceinline__ double rsqrt_fast(double s) {
+    const double y = __builtin_amdgcn_rsq(s);
+    const double e = __builtin_fma(-(s * y), y, 1.0);
+    return __builtin_fma(y * e, __builtin_fma(0.375, e, 0.5), y);
+}
+
+// err^(-1/5) for err in (5.9e-6, 1845): fp32 transcendental seed + one third-order Newton step on y^-5 = err (~1 ulp).
+// Stands in for the libm pow of SciPy's step-size controller (rk.py:158-168).
+__device__ __forceinline__ double inv_fifth_root(double err) {
+    const double y = (double)__builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf((float)err));
+    const double y2 = y * y, y4 = y2 * y2;
+    const double e = __builtin_fma(-err, y4 * y, 1.0);
+    return __builtin_fma(y * e, __builtin_fma(0.12, e, 0.2), y);
+}
+
 __device__ __forceinline__ V3 cross(const V3& a, const V3& b) {
     return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
@@ -98,21 +117,52 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// three standard normals: 24-bit uniforms in (0,1), fp32 Box-Muller on the transcendental unit
-// (v_log_f32 / v_sin_f32 / v_cos_f32 take log2 and revolutions natively).
-__device__ __forceinline__ V3 thermal_normals(uint64_t seed, uint64_t env_id, uint32_t env_step, uint32_t call_idx) {
-    uint32_t r[4];
-    philox4x32_10((uint32_t)env_id, (uint32_t)(env_id >> 32), env_step, call_idx, (uint32_t)seed,
-                  (uint32_t)(seed >> 32), r);
-    const float s = 1.0f / 16777216.0f;
-    const float u0 = ((float)(r[0] >> 8) + 0.5f) * s, u1 = ((float)(r[1] >> 8) + 0.5f) * s;
-    const float u2 = ((float)(r[2] >> 8) + 0.5f) * s, u3 = ((float)(r[3] >> 8) + 0.5f) * s;
-    const float m2ln2 = -1.3862943611198906f;   // -2 ln 2
-    const float ra = __builtin_sqrtf(m2ln2 * __builtin_amdgcn_logf(u0));
-    const float rb = __builtin_sqrtf(m2ln2 * __builtin_amdgcn_logf(u2));
-    return V3{(double)(ra * __builtin_amdgcn_cosf(u1)), (double)(ra * __builtin_amdgcn_sinf(u1)),
-              (double)(rb * __builtin_amdgcn_cosf(u3))};
-}
+// The thermal field needs three standard normals per RHS call.  Per (env, env step) the kernels run ONE stream:
+//   state   : xoshiro128++ (Blackman & Vigna), seeded by Philox4x32-10(key = seed, counter = (env_id, env_step, tag))
+//             -- counter-based seeding keeps every env's stream independent of the batch partition;
+//   normals : consecutive outputs (u_2p, u_2p+1) -> 24-bit uniforms in (0,1) -> one fp32 Box-Muller pair on the
+//             transcendental unit (v_log_f32 / v_sin_f32 / v_cos_f32 take log2 and revolutions natively);
+//   calls   : RHS call j takes normals 3j..3j+2, so even calls draw two pairs and keep the 4th normal, odd calls draw
+//             one pair and use the kept one first: 1.5 pairs per call, no waste.
+// (The reference draws from NumPy's global MT19937 per RHS call -- SURVEY H6 -- only the distribution can match.)
+struct NormalStream {
+    uint32_t s0, s1, s2, s3;
+    float carry;
+    __device__ __forceinline__ void init(uint64_t seed, uint64_t env_id, uint32_t env_step, uint32_t tag) {
+        uint32_t r[4];
+        philox4x32_10((uint32_t)env_id, (uint32_t)(env_id >> 32), env_step, tag, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+        s0 = r[0]; s1 = r[1]; s2 = r[2]; s3 = r[3] | 1u;     // never the all-zero state
+        carry = 0.0f;
+    }
+    __device__ __forceinline__ uint32_t next() {
+        const uint32_t a = s0 + s3;
+        const uint32_t result = ((a << 7) | (a >> 25)) + s0;
+        const uint32_t t = s1 << 9;
+        s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= t;
+        s3 = (s3 << 11) | (s3 >> 21);
+        return result;
+    }
+    __device__ __forceinline__ void pair(float& a, float& b) {
+        const float sc = 1.0f / 16777216.0f;
+        const float u0 = ((float)(next() >> 8) + 0.5f) * sc;
+        const float u1 = ((float)(next() >> 8) + 0.5f) * sc;
+        const float r = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));   // sqrt(-2 ln u0)
+        a = r * __builtin_amdgcn_cosf(u1);
+        b = r * __builtin_amdgcn_sinf(u1);
+    }
+    __device__ __forceinline__ V3 draw3_even() {
+        float a, b, c, d;
+        pair(a, b);
+        pair(c, d);
+        carry = d;
+        return V3{(double)a, (double)b, (double)c};
+    }
+    __device__ __forceinline__ V3 draw3_odd() {
+        float a, b;
+        pair(a, b);
+        return V3{(double)carry, (double)a, (double)b};
+    }
+};
 
 // ---- per-lane constant sets ----------------------------------------------------------------------
 struct SimpleK {            // A1/A2 constants of this lane's device class
@@ -124,29 +174,42 @@ struct LlgsK {              // A6 constants
     double hk, hex, alpha, gamma, hs;
 };
 
-// A1 + A2: SimpleLLGSSolver._compute_dmdt with h_applied = 0.  aJ = P*J/(ms*V) or 0 when the stage sees no current.
+// A1 + A2: SimpleLLGSSolver._compute_dmdt with h_applied = 0 (simple_solver.py:297-388), regrouped:
+//   H = c e + d z^ (+ hs z),  c = hk (m.e),  d = -ms m_z
+//   dm/dt = -geff (p + alpha m x p) + aJ m x (m x e),  p = m x H
+//         = -geff [ p + m x (alpha p + kJ t) ],         t = m x e,  kJ = aJ / (-geff)
+// 31 fp64 instructions (T = 0 K) instead of 42 for the literal form; every intermediate stays at or below the
+// magnitude of the reference's own intermediates, so overflow happens at the same sub-step.
 template <bool THERMAL>
-__device__ __forceinline__ V3 simple_rhs(const V3& m, const SimpleK& k, double aJ, const V3& z) {
-    const double c = k.hk * dot(m, k.e);
-    V3 h{c * k.e.x, c * k.e.y, c * k.e.z - k.ms * m.z};
-    if (THERMAL) h = V3{h.x + k.hs * z.x, h.y + k.hs * z.y, h.z + k.hs * z.z};   // simple_solver.py:384
-    const V3 p = cross(m, h);                 // precession
-    const V3 q = cross(m, p);                 // m x (m x H)
+__device__ __forceinline__ V3 simple_rhs(const V3& m, const SimpleK& k, double kJ, const V3& z) {
     const V3 t = cross(m, k.e);
-    const V3 u = cross(m, t);                 // m x (m x p), p = easy axis
-    return V3{-k.geff * (p.x + k.alpha * q.x) + aJ * u.x, -k.geff * (p.y + k.alpha * q.y) + aJ * u.y,
-              -k.geff * (p.z + k.alpha * q.z) + aJ * u.z};
+    const double c = k.hk * dot(m, k.e);
+    const double d = -k.ms * m.z;
+    V3 p;
+    if (THERMAL) {
+        const V3 h{__builtin_fma(k.hs, z.x, c * k.e.x), __builtin_fma(k.hs, z.y, c * k.e.y),
+                   __builtin_fma(k.hs, z.z, __builtin_fma(c, k.e.z, d))};                 // simple_solver.py:384,388
+        p = cross(m, h);
+    } else {
+        p = V3{__builtin_fma(c, t.x, d * m.y), __builtin_fma(c, t.y, -(d * m.x)), c * t.z};
+    }
+    const V3 w{__builtin_fma(k.alpha, p.x, kJ * t.x), __builtin_fma(k.alpha, p.y, kJ * t.y),
+               __builtin_fma(k.alpha, p.z, kJ * t.z)};
+    const V3 r{__builtin_fma(m.y, w.z, __builtin_fma(-m.z, w.y, p.x)), __builtin_fma(m.z, w.x, __builtin_fma(-m.x, w.z, p.y)),
+               __builtin_fma(m.x, w.y, __builtin_fma(-m.y, w.x, p.z))};
+    return V3{-k.geff * r.x, -k.geff * r.y, -k.geff * r.z};
 }
 
 // SimpleLLGSSolver._validate_magnetization (simple_solver.py:208-229).
 // returns 0 = normalised, 1 = reset to +z; sets zero_row when the quotient is the all-zero row m/inf.
 __device__ __forceinline__ int simple_validate(V3& m, bool& zero_row) {
     zero_row = false;
-    if (!finite3(m)) { m = V3{0.0, 0.0, 1.0}; return 1; }
-    const double mag = sqrt(dot(m, m));
-    if (mag < 1e-12) { m = V3{0.0, 0.0, 1.0}; return 1; }
-    m = V3{m.x / mag, m.y / mag, m.z / mag};   // finite / inf = 0: finite, so kept
-    zero_row = isinf(mag);
+    const double s = dot(m, m);
+    // non-finite components, or |m| < 1e-12 (s < 1e-24): the reference's "safe default" [0,0,1]
+    if (!finite3(m) || s < 1e-24) { m = V3{0.0, 0.0, 1.0}; return 1; }
+    const double inv = rsqrt_fast(s);           // s = inf (finite m, overflowed norm) -> inv = 0 -> zero row
+    m = V3{m.x * inv, m.y * inv, m.z * inv};
+    zero_row = isinf(s);
     return 0;
 }
 
@@ -205,48 +268,52 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
     dt = T / (double)n;
     o.n = n;
     o.work = n;
-    const double half_dt = 0.5 * dt;
+    const double half_dt = 0.5 * dt, sixth_dt = dt / 6.0;
     const bool useJ = fabs(J) > 1e-12;                                     // simple_solver.py:326
     const double aJ = useJ ? (pol * J) / msv : 0.0;                        // simple_solver.py:330
+    const double kJ = aJ / (-k.geff);                                      // see simple_rhs
+    // Stage times are t_i = i*dt (np.linspace), t_i + dt/2, t_i + dt and the pulse is on while t <= T
+    // (spin_torque_env.py:442-443).  For i <= n-2 every stage time is below T by at least dt/2; only the last
+    // sub-step's k2/k3/k4 stages can land an ulp beyond T and see J = 0, so only that one is tested,
+    // in exactly the reference's roundings.
+    const double t_last = mul_x((double)(n - 1), dt);
+    const double kJ2_last = (add_x(t_last, mul_x(dt, 0.5)) <= T) ? kJ : 0.0;
+    const double kJ4_last = (add_x(t_last, dt) <= T) ? kJ : 0.0;
     bool fail = false;
     const V3 zero{0.0, 0.0, 0.0};
+    NormalStream ns;
+    if (THERMAL) ns.init(rk.seed, rk.env_id, rk.env_step, 0u);
     if (RECORD) rec.put(0, 0.0, m, 0.0);
     for (int i = 0; i < n; ++i) {
-        // t_i = linspace(0, T, n+1)[i] = i*step; stage times t_i + dt/2, t_i + dt; the pulse is on while
-        // t <= T (spin_torque_env.py:442-443).  Only the last stages can land 1 ulp beyond T.
-        const double ti = mul_x((double)i, dt);
-        const double a2 = (add_x(ti, mul_x(dt, 0.5)) <= T) ? aJ : 0.0;
-        const double a4 = (add_x(ti, dt) <= T) ? aJ : 0.0;
+        const bool last = (i == n - 1);
+        const double kJ2 = last ? kJ2_last : kJ, kJ4 = last ? kJ4_last : kJ;
         V3 mn;
         if (METHOD == 1) {
-            const V3 h0 = THERMAL ? thermal_normals(rk.seed, rk.env_id, rk.env_step, 4u * i) : zero;
-            const V3 f = simple_rhs<THERMAL>(m, k, aJ, h0);
-            mn = V3{m.x + dt * f.x, m.y + dt * f.y, m.z + dt * f.z};
+            V3 z0 = zero;
+            if (THERMAL) z0 = (i & 1) ? ns.draw3_odd() : ns.draw3_even();
+            const V3 f = simple_rhs<THERMAL>(m, k, kJ, z0);
+            mn = V3{m.x + dt * f.x, m.y + dt * f.y, m.z + dt * f.z};      // simple_solver.py:275-276
         } else {
             V3 z0 = zero, z1 = zero, z2 = zero, z3 = zero;
-            if (THERMAL) {
-                z0 = thermal_normals(rk.seed, rk.env_id, rk.env_step, 4u * i);
-                z1 = thermal_normals(rk.seed, rk.env_id, rk.env_step, 4u * i + 1u);
-                z2 = thermal_normals(rk.seed, rk.env_id, rk.env_step, 4u * i + 2u);
-                z3 = thermal_normals(rk.seed, rk.env_id, rk.env_step, 4u * i + 3u);
+            if (THERMAL) {   // 12 normals = 6 Box-Muller pairs per sub-step
+                z0 = ns.draw3_even(); z1 = ns.draw3_odd(); z2 = ns.draw3_even(); z3 = ns.draw3_odd();
             }
-            const V3 f1 = simple_rhs<THERMAL>(m, k, aJ, z0);
+            const V3 f1 = simple_rhs<THERMAL>(m, k, kJ, z0);
             const V3 y2{m.x + half_dt * f1.x, m.y + half_dt * f1.y, m.z + half_dt * f1.z};
-            const V3 f2 = simple_rhs<THERMAL>(y2, k, a2, z1);
+            const V3 f2 = simple_rhs<THERMAL>(y2, k, kJ2, z1);
             const V3 y3{m.x + half_dt * f2.x, m.y + half_dt * f2.y, m.z + half_dt * f2.z};
-            const V3 f3 = simple_rhs<THERMAL>(y3, k, a2, z2);
+            const V3 f3 = simple_rhs<THERMAL>(y3, k, kJ2, z2);
             const V3 y4{m.x + dt * f3.x, m.y + dt * f3.y, m.z + dt * f3.z};
-            const V3 f4 = simple_rhs<THERMAL>(y4, k, a4, z3);
-            // m + (k1 + 2 k2 + 2 k3 + k4)/6 with k = dt*f
-            const double w = dt / 6.0;
-            mn = V3{m.x + w * ((f1.x + 2.0 * f2.x) + (2.0 * f3.x + f4.x)),
-                    m.y + w * ((f1.y + 2.0 * f2.y) + (2.0 * f3.y + f4.y)),
-                    m.z + w * ((f1.z + 2.0 * f2.z) + (2.0 * f3.z + f4.z))};
+            const V3 f4 = simple_rhs<THERMAL>(y4, k, kJ4, z3);
+            // m + (k1 + 2 k2 + 2 k3 + k4)/6 with k = dt*f                  simple_solver.py:290-295
+            mn = V3{m.x + sixth_dt * ((f1.x + 2.0 * f2.x) + (2.0 * f3.x + f4.x)),
+                    m.y + sixth_dt * ((f1.y + 2.0 * f2.y) + (2.0 * f3.y + f4.y)),
+                    m.z + sixth_dt * ((f1.z + 2.0 * f2.z) + (2.0 * f3.z + f4.z))};
         }
         resets += simple_validate(mn, zr);                                 // simple_solver.py:168
         fail |= zr;                                                        // robust_solver.py:192-205
         m = mn;
-        if (RECORD) rec.put(i + 1, (i + 1 == n) ? T : mul_x((double)(i + 1), dt), m, 0.0);
+        if (RECORD) rec.put(i + 1, last ? T : mul_x((double)(i + 1), dt), m, 0.0);
     }
     o.resets = resets;
     if (fail) return o;
@@ -258,9 +325,12 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
 // A6: LLGSSolver.solve::llgs_rhs.  bJ = beta*J, bpJ = beta'*J (0 when |J| < 1e-12 or the pulse is over).
 template <bool THERMAL>
 __device__ __forceinline__ V3 llgs_rhs(const V3& y, const LlgsK& k, double bJ, double bpJ, const V3& z) {
-    const double nn = sqrt(dot(y, y));
+    const double ss = dot(y, y);
     V3 m{0.0, 0.0, 1.0};
-    if (nn > 1e-12) m = V3{y.x / nn, y.y / nn, y.z / nn};                  // llgs_solver.py:97-101
+    if (ss > 1e-24) {                                                      // |y| > 1e-12, llgs_solver.py:97-101
+        const double inv = rsqrt_fast(ss);
+        m = V3{y.x * inv, y.y * inv, y.z * inv};
+    }
     const double c = k.hk * dot(m, k.r);
     V3 h{(c * k.r.x + k.d.x * m.x) + k.hex * m.x, (c * k.r.y + k.d.y * m.y) + k.hex * m.y,
          (c * k.r.z + k.d.z * m.z) + k.hex * m.z};
@@ -307,27 +377,28 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
     SolveOut o{m0, 0, 0, 0, false};
     const bool useJ = !(fabs(J) < 1e-12);                                   // llgs_solver.py:222
     const double bJ = useJ ? beta * J : 0.0, bpJ = useJ ? betap * J : 0.0;
-    uint32_t call = 0;
     const V3 zero{0.0, 0.0, 0.0};
-    auto fun = [&](double t, const V3& y) -> V3 {
-        const bool on = t <= T;                                             // spin_torque_env.py:442-443
+    NormalStream ns;
+    if (THERMAL) ns.init(rk.seed, rk.env_id, rk.env_step, 0u);
+    // RHS call with the pulse gate of spin_torque_env.py:442-443; EVEN selects the normal-stream phase (calls alternate)
+    auto fun = [&](double t, const V3& y, bool even) -> V3 {
+        const bool on = t <= T;
         V3 z = zero;
-        if (THERMAL) z = thermal_normals(rk.seed, rk.env_id, rk.env_step, call);
-        ++call;
+        if (THERMAL) z = even ? ns.draw3_even() : ns.draw3_odd();
         return llgs_rhs<THERMAL>(y, k, on ? bJ : 0.0, on ? bpJ : 0.0, z);
     };
-    const double n0 = sqrt(dot(m0, m0));                                    // llgs_solver.py:76
-    V3 y{m0.x / n0, m0.y / n0, m0.z / n0};
+    const double n0 = rsqrt_fast(dot(m0, m0));                              // llgs_solver.py:76
+    V3 y{m0.x * n0, m0.y * n0, m0.z * n0};
     double t = 0.0;
     int32_t npts = 0;
     auto emit = [&]() {
-        const double nn = sqrt(dot(y, y));                                  // llgs_solver.py:152-153
-        o.m = V3{y.x / nn, y.y / nn, y.z / nn};
+        const double inv = rsqrt_fast(dot(y, y));                           // llgs_solver.py:152-153
+        o.m = V3{y.x * inv, y.y * inv, y.z * inv};
         if (RECORD) rec.put(npts, t, o.m, rec.e ? llgs_energy(o.m, ek) : 0.0);
         ++npts;
     };
     emit();
-    V3 f = fun(t, y);
+    V3 f = fun(t, y, true);
     double h_abs;
     {   // select_initial_step (common.py:68-134), order = error_estimator_order = 4
         const V3 sc{atol + fabs(y.x) * rtol, atol + fabs(y.y) * rtol, atol + fabs(y.z) * rtol};
@@ -336,69 +407,73 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
         double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
         h0 = fmin(h0, T);
         const V3 y1{y.x + h0 * f.x, y.y + h0 * f.y, y.z + h0 * f.z};
-        const V3 f1 = fun(add_x(t, h0), y1);
+        const V3 f1 = fun(add_x(t, h0), y1, false);
         const double d2 = rms3(V3{(f1.x - f.x) / sc.x, (f1.y - f.y) / sc.y, (f1.z - f.z) / sc.z}) / h0;
         const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : pow(0.01 / fmax(d1, d2), 0.2);
         h_abs = fmin(fmin(100.0 * h0, h1), fmin(T, max_step));
     }
-    bool ok = true;
+    // SciPy nests "while not finished: step()" around "while not step_accepted: attempt" (ivp.py:654-661, base.py:175-206,
+    // rk.py:111-181).  Here ONE flat loop runs one attempt per iteration and an accepted attempt performs the outer
+    // loop's bookkeeping itself: same sequence of attempts per lane, but a wavefront needs max-over-lanes(total attempts)
+    // iterations instead of sum-over-steps(max-over-lanes(attempts of that step)).
+    auto min_step_at = [](double tt) {   // 10 * |nextafter(t, inf) - t|, t >= 0                      rk.py:119
+        return 10.0 * (__longlong_as_double(__double_as_longlong(tt) + 1) - tt);
+    };
+    bool ok = true, rejected = false;
     int64_t attempts = 0;
-    while (t != T) {                                                        // base.py:175-206, ivp.py:654-661
-        const double ulp = __longlong_as_double(__double_as_longlong(t) + 1) - t;   // nextafter(t, inf) - t, t >= 0
-        const double min_step = 10.0 * ulp;                                 // rk.py:119
-        h_abs = h_abs > max_step ? max_step : (h_abs < min_step ? min_step : h_abs);
-        bool accepted = false, rejected = false;
-        V3 y_new = y, f_new = f;
-        double t_new = t;
-        while (!accepted) {
-            if (h_abs < min_step || attempts >= max_attempts) { ok = false; break; }
-            ++attempts;
-            t_new = add_x(t, h_abs);
-            if (t_new - T > 0.0) t_new = T;
-            const double h = sub_x(t_new, t);
-            h_abs = fabs(h);
-            // rk_step (rk.py:14-70); stage times must not be contracted into FMAs (they gate the pulse)
-            const V3 k1 = f;
-            const V3 k2 = fun(add_x(t, mul_x(C2, h)), V3{y.x + (k1.x * A21) * h, y.y + (k1.y * A21) * h, y.z + (k1.z * A21) * h});
-            const V3 k3 = fun(add_x(t, mul_x(C3, h)),
-                              V3{y.x + (k1.x * A31 + k2.x * A32) * h, y.y + (k1.y * A31 + k2.y * A32) * h,
-                                 y.z + (k1.z * A31 + k2.z * A32) * h});
-            const V3 k4 = fun(add_x(t, mul_x(C4, h)),
-                              V3{y.x + (k1.x * A41 + k2.x * A42 + k3.x * A43) * h, y.y + (k1.y * A41 + k2.y * A42 + k3.y * A43) * h,
-                                 y.z + (k1.z * A41 + k2.z * A42 + k3.z * A43) * h});
-            const V3 k5 = fun(add_x(t, mul_x(C5, h)),
-                              V3{y.x + (k1.x * A51 + k2.x * A52 + k3.x * A53 + k4.x * A54) * h,
-                                 y.y + (k1.y * A51 + k2.y * A52 + k3.y * A53 + k4.y * A54) * h,
-                                 y.z + (k1.z * A51 + k2.z * A52 + k3.z * A53 + k4.z * A54) * h});
-            const V3 k6 = fun(add_x(t, h),
-                              V3{y.x + (k1.x * A61 + k2.x * A62 + k3.x * A63 + k4.x * A64 + k5.x * A65) * h,
-                                 y.y + (k1.y * A61 + k2.y * A62 + k3.y * A63 + k4.y * A64 + k5.y * A65) * h,
-                                 y.z + (k1.z * A61 + k2.z * A62 + k3.z * A63 + k4.z * A64 + k5.z * A65) * h});
-            y_new = V3{y.x + h * (k1.x * B1 + k3.x * B3 + k4.x * B4 + k5.x * B5 + k6.x * B6),
+    double min_step = min_step_at(t);
+    h_abs = h_abs > max_step ? max_step : (h_abs < min_step ? min_step : h_abs);          // rk.py:121-126
+    while (t != T) {
+        if (h_abs < min_step || attempts >= max_attempts) { ok = false; break; }          // rk.py:132-133 (+ budget)
+        ++attempts;
+        double t_new = add_x(t, h_abs);
+        if (t_new - T > 0.0) t_new = T;
+        const double h = sub_x(t_new, t);
+        h_abs = fabs(h);
+        // rk_step (rk.py:14-70); stage times must not be contracted into FMAs (they gate the pulse)
+        const V3 k1 = f;
+        const V3 k2 = fun(add_x(t, mul_x(C2, h)), V3{y.x + (k1.x * A21) * h, y.y + (k1.y * A21) * h, y.z + (k1.z * A21) * h}, true);
+        const V3 k3 = fun(add_x(t, mul_x(C3, h)),
+                          V3{y.x + (k1.x * A31 + k2.x * A32) * h, y.y + (k1.y * A31 + k2.y * A32) * h,
+                             y.z + (k1.z * A31 + k2.z * A32) * h}, false);
+        const V3 k4 = fun(add_x(t, mul_x(C4, h)),
+                          V3{y.x + (k1.x * A41 + k2.x * A42 + k3.x * A43) * h, y.y + (k1.y * A41 + k2.y * A42 + k3.y * A43) * h,
+                             y.z + (k1.z * A41 + k2.z * A42 + k3.z * A43) * h}, true);
+        const V3 k5 = fun(add_x(t, mul_x(C5, h)),
+                          V3{y.x + (k1.x * A51 + k2.x * A52 + k3.x * A53 + k4.x * A54) * h,
+                             y.y + (k1.y * A51 + k2.y * A52 + k3.y * A53 + k4.y * A54) * h,
+                             y.z + (k1.z * A51 + k2.z * A52 + k3.z * A53 + k4.z * A54) * h}, false);
+        const V3 k6 = fun(add_x(t, h),
+                          V3{y.x + (k1.x * A61 + k2.x * A62 + k3.x * A63 + k4.x * A64 + k5.x * A65) * h,
+                             y.y + (k1.y * A61 + k2.y * A62 + k3.y * A63 + k4.y * A64 + k5.y * A65) * h,
+                             y.z + (k1.z * A61 + k2.z * A62 + k3.z * A63 + k4.z * A64 + k5.z * A65) * h}, true);
+        const V3 y_new{y.x + h * (k1.x * B1 + k3.x * B3 + k4.x * B4 + k5.x * B5 + k6.x * B6),
                        y.y + h * (k1.y * B1 + k3.y * B3 + k4.y * B4 + k5.y * B5 + k6.y * B6),
                        y.z + h * (k1.z * B1 + k3.z * B3 + k4.z * B4 + k5.z * B5 + k6.z * B6)};
-            f_new = fun(add_x(t, h), y_new);
-            const V3 ev{(k1.x * E1 + k3.x * E3 + k4.x * E4 + k5.x * E5 + k6.x * E6 + f_new.x * E7) * h,
-                        (k1.y * E1 + k3.y * E3 + k4.y * E4 + k5.y * E5 + k6.y * E6 + f_new.y * E7) * h,
-                        (k1.z * E1 + k3.z * E3 + k4.z * E4 + k5.z * E5 + k6.z * E6 + f_new.z * E7) * h};
-            const V3 sc{atol + fmax(fabs(y.x), fabs(y_new.x)) * rtol, atol + fmax(fabs(y.y), fabs(y_new.y)) * rtol,
-                        atol + fmax(fabs(y.z), fabs(y_new.z)) * rtol};
-            const double err = rms3(V3{ev.x / sc.x, ev.y / sc.y, ev.z / sc.z});
-            if (err < 1.0) {
-                double factor = (err == 0.0) ? 10.0 : fmin(10.0, 0.9 * pow(err, -0.2));
-                if (rejected) factor = fmin(1.0, factor);
-                h_abs *= factor;
-                accepted = true;
-            } else {
-                h_abs *= fmax(0.2, 0.9 * pow(err, -0.2));    // NaN error norms land here too, as in SciPy
-                rejected = true;
-            }
+        const V3 f_new = fun(add_x(t, h), y_new, false);
+        const V3 ev{(k1.x * E1 + k3.x * E3 + k4.x * E4 + k5.x * E5 + k6.x * E6 + f_new.x * E7) * h,
+                    (k1.y * E1 + k3.y * E3 + k4.y * E4 + k5.y * E5 + k6.y * E6 + f_new.y * E7) * h,
+                    (k1.z * E1 + k3.z * E3 + k4.z * E4 + k5.z * E5 + k6.z * E6 + f_new.z * E7) * h};
+        const V3 sc{atol + fmax(fabs(y.x), fabs(y_new.x)) * rtol, atol + fmax(fabs(y.y), fabs(y_new.y)) * rtol,
+                    atol + fmax(fabs(y.z), fabs(y_new.z)) * rtol};
+        const double err = rms3(V3{ev.x / sc.x, ev.y / sc.y, ev.z / sc.z});
+        // 0.9 * err^-0.2 saturates at MAX_FACTOR = 10 for err <= 0.09^5 and at MIN_FACTOR = 0.2 for err >= 4.5^5
+        if (err < 1.0) {
+            double factor = (err <= 5.9049e-6) ? 10.0 : fmin(10.0, 0.9 * inv_fifth_root(err));   // also err == 0
+            if (rejected) factor = fmin(1.0, factor);
+            h_abs *= factor;
+            // step accepted: advance, record, and do the next step()'s prologue
+            t = t_new; y = y_new; f = f_new;
+            emit();
+            rejected = false;
+            min_step = min_step_at(t);
+            h_abs = h_abs > max_step ? max_step : (h_abs < min_step ? min_step : h_abs);
+        } else {
+            // NaN error norms land here too (nan < 1 is False), as in SciPy; fmax(0.2, NaN) = 0.2
+            const double g = (err >= 1845.28125) ? 0.2 : fmax(0.2, 0.9 * inv_fifth_root(err));
+            h_abs *= g;
+            rejected = true;
         }
-        if (!ok) break;
-        t = t_new;
-        y = y_new;
-        f = f_new;
-        emit();
     }
     o.n = npts - 1;
     o.work = attempts;

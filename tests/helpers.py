@@ -46,14 +46,17 @@ def _philox(ctr, key):
 
 
 def device_reset_draw(seed, env_id, rng_step, targets):
-    """Restates the kernels' device-side reset draw (csrc/spintorque_hip.hip: device_reset_draw)."""
-    s = (seed ^ RESET_KEY_XOR) & 0xFFFFFFFFFFFFFFFF
-    z = oracle.thermal_normals(s, env_id, rng_step, 0xFFFFFFFF)
+    """The kernels' device-side reset draw (csrc/spintorque_hip.hip: device_reset_draw) through its oracle restatement."""
+    L = oracle.lib()
+    L.stgo_reset_draw.restype = None
+    L.stgo_reset_draw.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    z = np.zeros(3)
+    idx = C.c_int(0)
+    L.stgo_reset_draw(seed & 0xFFFFFFFFFFFFFFFF, env_id, rng_step, len(targets), z.ctypes.data_as(C.POINTER(C.c_double)),
+                      C.byref(idx))
     n = np.sqrt((z[0] * z[0] + z[1] * z[1]) + z[2] * z[2])
     m = np.array([0.0, 0.0, 1.0]) if n < 1e-12 else z / n
-    r = _philox([env_id & 0xFFFFFFFF, env_id >> 32, rng_step, 0xFFFFFFFE], [s & 0xFFFFFFFF, s >> 32])
-    idx = (r[0] * len(targets)) >> 32
-    return m, np.array(targets[idx], dtype=np.float64)
+    return m, np.array(targets[idx.value], dtype=np.float64)
 
 
 class OracleBackend:
