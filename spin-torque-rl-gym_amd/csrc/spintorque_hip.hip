@@ -48,6 +48,7 @@ struct StepArgs {
     int32_t ncls;
     const void* actions;          // [K][2][N]
     int32_t K, out_every, autoreset;
+    const uint32_t* perm;         // lane -> env (duration-sorted schedule) or nullptr
     unsigned long long* counters; // [4]: env-steps, integrator sub-steps/attempts, RHS evaluations, no-op steps
     float* obs;                   // [K or 1][12][N]
     float* reward;                // [K or 1][N]
@@ -98,7 +99,7 @@ __device__ __forceinline__ LlgsEnergyK load_energy(const double* r) {
     return LlgsEnergyK{r[C_KUV], r[C_EDEMAG], V3{r[C_RX], r[C_RY], r[C_RZ]}, V3{r[C_NX], r[C_NY], r[C_NZ]}};
 }
 
-template <int SOLVER, bool THERMAL, bool RECORD>
+template <int SOLVER, bool THERMAL, bool RECORD, bool AXIS_Z>
 __device__ __forceinline__ SolveOut run_solver(const V3& m, double J, double T, const double* row, const CfgView& c,
                                                const RngKey& rk, const Recorder& rec) {
     if (SOLVER == STG_SOLVER_RK45) {
@@ -109,7 +110,7 @@ __device__ __forceinline__ SolveOut run_solver(const V3& m, double J, double T, 
                                            c.max_attempts, rk, rec, ek);
     }
     const SimpleK k = load_simple(row);
-    return simple_solve<SOLVER == STG_SOLVER_EULER ? 1 : 0, THERMAL, RECORD>(m, J, T, k, row[C_POL], row[C_MSV],
+    return simple_solve<SOLVER == STG_SOLVER_EULER ? 1 : 0, THERMAL, RECORD, AXIS_Z>(m, J, T, k, row[C_POL], row[C_MSV],
                                                                            row[C_VALID] != 0.0, c.temperature,
                                                                            c.max_step, rk, rec);
 }
@@ -167,11 +168,14 @@ __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned long 
 // ------------------------------------------------------------------------------------------------
 // env.step kernel (A10-A14 around the solver), K fused steps per launch
 // ------------------------------------------------------------------------------------------------
-template <int SOLVER, bool THERMAL, bool MULTI, typename AT>
+template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, typename AT>
 __global__ void __launch_bounds__(64) stg_step_kernel(const StepArgs a) {
     __shared__ double s_tab[MULTI ? STG_MAX_CLASSES * C_COUNT : 1];
-    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    const bool in_range = i < a.N;
+    const int64_t lane_slot = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool in_range = lane_slot < a.N;
+    // duration-sorted schedule: slot j of the launch integrates env perm[j], so the 64 lanes of a wavefront have
+    // (nearly) equal trip counts; all state and outputs stay at the env's own index
+    const int64_t i = in_range ? (a.perm ? (int64_t)a.perm[lane_slot] : lane_slot) : 0;
     const double* row = class_row<MULTI>(a.ctab, a.cls, a.ncls, i, in_range, s_tab);
     if (!in_range) return;
     const int64_t N = a.N;
@@ -209,7 +213,7 @@ __global__ void __launch_bounds__(64) stg_step_kernel(const StepArgs a) {
         } else {
             const double prev_align = dot(m, tgt);                                   // spin_torque_env.py:338-339
             const RngKey rk{a.c.seed, env_id, rng};
-            const SolveOut so = run_solver<SOLVER, THERMAL, false>(m, J, T, row, a.c, rk, norec);
+            const SolveOut so = run_solver<SOLVER, THERMAL, false, AXIS_Z>(m, J, T, row, a.c, rk, norec);
             if (fabs(J) > 1e-12) {                                                   // spin_torque_env.py:474-480
                 const V3 ref{row[C_REFX], row[C_REFY], row[C_REFZ]};
                 const double r = resistance(m, (int)row[C_DEVTYPE], row[C_RP], row[C_RAP], row[C_TMR], ref, row[C_RSERIES]);
@@ -273,7 +277,7 @@ __global__ void __launch_bounds__(64) stg_solve_kernel(const SolveArgs a) {
     const V3 m0{a.m0[i], a.m0[N + i], a.m0[2 * N + i]};
     const RngKey rk{a.c.seed, (uint64_t)(a.env_id0 + i), a.env_step};
     const Recorder rec{a.traj_t, a.traj_m, a.traj_e, N, i, a.traj_cap};
-    const SolveOut so = run_solver<SOLVER, THERMAL, RECORD>(m0, a.J[i], a.T[i], row, a.c, rk, rec);
+    const SolveOut so = run_solver<SOLVER, THERMAL, RECORD, false>(m0, a.J[i], a.T[i], row, a.c, rk, rec);
     a.m_final[i] = so.m.x; a.m_final[N + i] = so.m.y; a.m_final[2 * N + i] = so.m.z;
     if (a.n_points) a.n_points[i] = so.n;
     if (a.success) a.success[i] = so.ok ? 1 : 0;
@@ -345,6 +349,74 @@ __global__ void stg_normals_kernel(uint64_t seed, int64_t env_id0, int64_t N, ui
 }
 
 // ------------------------------------------------------------------------------------------------
+// lane schedule: counting sort of the envs by this step's integration work (descending)
+// ------------------------------------------------------------------------------------------------
+// The trip count of a lane is set by its pulse duration (RK4: n = T/dt sub-steps; RK45: attempts ~ T / 0.65 ps), which
+// the agent chooses per env: U[0.1, 1] ns gives a mean/max ratio of 0.55 inside a wavefront.  Three tiny kernels
+// (histogram in LDS -> scan -> scatter) build a permutation with equal-work envs adjacent; cost ~10 us per step.
+constexpr int PLAN_BUCKETS = 1024;
+
+struct PlanArgs {
+    const void* actions;      // [2][N] of the first fused step
+    int32_t act_f64;
+    int64_t N;
+    double max_current, max_duration;
+    const uint8_t* done;      // with skip_done: finished envs go last (no work)
+    int32_t skip_done;
+    uint16_t* key;
+    uint32_t *hist, *cursor, *perm;
+};
+
+__device__ __forceinline__ int plan_key(const PlanArgs& a, int64_t i) {
+    double J, T;
+    if (a.act_f64) parse_action<double>(((const double*)a.actions)[i], ((const double*)a.actions)[a.N + i], a.max_current, a.max_duration, J, T);
+    else parse_action<float>(((const float*)a.actions)[i], ((const float*)a.actions)[a.N + i], a.max_current, a.max_duration, J, T);
+    if (a.skip_done && a.done[i]) return PLAN_BUCKETS - 1;
+    const double w = fmax(T, 1e-10) / a.max_duration;          // below 0.1 ns the RK4 sub-step count stays at ~100
+    int b = (int)(w * (PLAN_BUCKETS - 1));
+    b = b < 0 ? 0 : (b > PLAN_BUCKETS - 2 ? PLAN_BUCKETS - 2 : b);
+    return (PLAN_BUCKETS - 2) - b;                             // descending work: long pulses are dispatched first
+}
+
+__global__ void __launch_bounds__(256) stg_plan_hist_kernel(const PlanArgs a) {
+    __shared__ uint32_t h[PLAN_BUCKETS];
+    for (int j = threadIdx.x; j < PLAN_BUCKETS; j += 256) h[j] = 0;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < a.N) {
+        const int k = plan_key(a, i);
+        a.key[i] = (uint16_t)k;
+        atomicAdd(&h[k], 1u);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < PLAN_BUCKETS; j += 256)
+        if (h[j]) atomicAdd(&a.hist[j], h[j]);
+}
+
+__global__ void __launch_bounds__(PLAN_BUCKETS) stg_plan_scan_kernel(uint32_t* hist, uint32_t* cursor) {
+    __shared__ uint32_t s[PLAN_BUCKETS];
+    const int t = threadIdx.x;
+    const uint32_t v = hist[t];
+    s[t] = v;
+    __syncthreads();
+    for (int off = 1; off < PLAN_BUCKETS; off <<= 1) {         // Hillis-Steele inclusive scan
+        const uint32_t add = (t >= off) ? s[t - off] : 0u;
+        __syncthreads();
+        s[t] += add;
+        __syncthreads();
+    }
+    cursor[t] = s[t] - v;                                      // exclusive start of bucket t
+    hist[t] = 0;                                               // ready for the next step
+}
+
+__global__ void __launch_bounds__(256) stg_plan_scatter_kernel(const PlanArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.N) return;
+    const uint32_t pos = atomicAdd(&a.cursor[a.key[i]], 1u);
+    a.perm[pos] = (uint32_t)i;
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -371,7 +443,10 @@ struct stg_ctx {
     int32_t ncls = 0;
     const uint8_t* cls = nullptr;     // caller-owned device pointer
     unsigned long long* counters = nullptr;
+    uint32_t *perm = nullptr, *hist = nullptr, *cursor = nullptr;
+    uint16_t* key = nullptr;
     bool have_params = false, have_state = false;
+    bool axis_z = false;              // every class has easy axis = +z exactly: the specialised Simple RHS applies
 };
 
 static CfgView cfg_view(const stg_config& c) {
@@ -419,7 +494,9 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
     const size_t N = (size_t)n_envs;
     const size_t r8 = al(N * 8), r4 = al(N * 4), r1 = al(N);
-    const size_t total = 7 * r8 + 2 * r4 + r1 + al(sizeof(double) * STG_MAX_CLASSES * C_COUNT) + 256;
+    const size_t r2 = al(N * 2);
+    const size_t total = 7 * r8 + 3 * r4 + r1 + r2 + al(sizeof(double) * STG_MAX_CLASSES * C_COUNT) + 256 +
+                         2 * al(sizeof(uint32_t) * PLAN_BUCKETS);
     hipError_t e = hipMalloc(&c->slab, total);
     if (e != hipSuccess) { delete c; return fail(STG_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     e = hipMemset(c->slab, 0, total);
@@ -431,7 +508,11 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     c->s.rng = (uint32_t*)p; p += r4;
     c->s.done = (uint8_t*)p; p += r1;
     c->ctab = (double*)p; p += al(sizeof(double) * STG_MAX_CLASSES * C_COUNT);
-    c->counters = (unsigned long long*)p;
+    c->counters = (unsigned long long*)p; p += 256;
+    c->perm = (uint32_t*)p; p += r4;
+    c->key = (uint16_t*)p; p += r2;
+    c->hist = (uint32_t*)p; p += al(sizeof(uint32_t) * PLAN_BUCKETS);
+    c->cursor = (uint32_t*)p;
     *out = c;
     return STG_OK;
 }
@@ -489,6 +570,9 @@ int stg_set_params(stg_ctx* ctx, const stg_device_params* table, int32_t n_class
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemcpy(ctx->ctab, ctx->h_ctab, sizeof(double) * n_classes * C_COUNT, hipMemcpyHostToDevice));
     ctx->ncls = n_classes;
+    ctx->axis_z = true;
+    for (int k = 0; k < n_classes; ++k)
+        ctx->axis_z = ctx->axis_z && ctx->h_ctab[k][C_EX] == 0.0 && ctx->h_ctab[k][C_EY] == 0.0 && ctx->h_ctab[k][C_EZ] == 1.0;
     ctx->cls = n_classes > 1 ? cls : nullptr;
     ctx->have_params = true;
     return STG_OK;
@@ -520,17 +604,23 @@ int stg_reset(stg_ctx* ctx, const uint8_t* mask, const double* init_m, const dou
 }
 
 extern "C++" {
-template <int SOLVER, bool THERMAL, bool MULTI>
+template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z>
 static void launch_step(const StepArgs& a, int act_f64, hipStream_t st) {
     if (act_f64)
-        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, double>), grid_for(a.N), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, double>), grid_for(a.N), dim3(64), 0, st, a);
     else
-        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, float>), grid_for(a.N), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, float>), grid_for(a.N), dim3(64), 0, st, a);
 }
+template <int SOLVER, bool AXIS_Z>
+static void dispatch_step2(const StepArgs& a, bool thermal, bool multi, int act_f64, hipStream_t st) {
+    if (thermal) { if (multi) launch_step<SOLVER, true, true, AXIS_Z>(a, act_f64, st); else launch_step<SOLVER, true, false, AXIS_Z>(a, act_f64, st); }
+    else { if (multi) launch_step<SOLVER, false, true, AXIS_Z>(a, act_f64, st); else launch_step<SOLVER, false, false, AXIS_Z>(a, act_f64, st); }
+}
+// axis_z selects the easy-axis = +z specialisation of the Simple RHS (RK45 has no such variant)
 template <int SOLVER>
-static void dispatch_step(const StepArgs& a, bool thermal, bool multi, int act_f64, hipStream_t st) {
-    if (thermal) { if (multi) launch_step<SOLVER, true, true>(a, act_f64, st); else launch_step<SOLVER, true, false>(a, act_f64, st); }
-    else { if (multi) launch_step<SOLVER, false, true>(a, act_f64, st); else launch_step<SOLVER, false, false>(a, act_f64, st); }
+static void dispatch_step(const StepArgs& a, bool thermal, bool multi, bool axis_z, int act_f64, hipStream_t st) {
+    if (SOLVER != STG_SOLVER_RK45 && axis_z) dispatch_step2<SOLVER, true>(a, thermal, multi, act_f64, st);
+    else dispatch_step2<SOLVER, false>(a, thermal, multi, act_f64, st);
 }
 }  // extern "C++"
 
@@ -546,16 +636,35 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
     a.s = ctx->s; a.c = cfg_view(ctx->cfg); a.N = ctx->N; a.env_id0 = ctx->env_id0;
     a.ctab = ctx->ctab; a.cls = ctx->cls; a.ncls = ctx->ncls;
     a.counters = ctx->counters;
+    hipStream_t st = (hipStream_t)stream;
+    a.perm = nullptr;
+    // lane_sort: 0 = automatic (sort when the launch has more than two wavefronts per SIMD for the dispatcher to balance,
+    // or with the adaptive RK45 whose lanes also differ in attempts per step; below that the ~25 us of the three plan
+    // kernels cost more than they save), 1 = always, -1 = never
+    const bool want_sort = ctx->cfg.lane_sort > 0 ||
+                           (ctx->cfg.lane_sort == 0 && (ctx->N > 2 * 64 * 1024 || ctx->cfg.solver == STG_SOLVER_RK45));
+    if (want_sort && ctx->N > 64) {
+        if (ctx->N > 0xFFFFFFFFll) return fail(STG_E_INVALID, "lane sort supports up to 2^32 envs per context");
+        PlanArgs pa{};
+        pa.actions = actions; pa.act_f64 = act_f64; pa.N = ctx->N;
+        pa.max_current = ctx->cfg.max_current; pa.max_duration = ctx->cfg.max_duration;
+        pa.done = ctx->s.done; pa.skip_done = (ctx->cfg.skip_done && !autoreset) ? 1 : 0;
+        pa.key = ctx->key; pa.hist = ctx->hist; pa.cursor = ctx->cursor; pa.perm = ctx->perm;
+        const dim3 g((unsigned)((ctx->N + 255) / 256));
+        hipLaunchKernelGGL(stg_plan_hist_kernel, g, dim3(256), 0, st, pa);
+        hipLaunchKernelGGL(stg_plan_scan_kernel, dim3(1), dim3(PLAN_BUCKETS), 0, st, ctx->hist, ctx->cursor);
+        hipLaunchKernelGGL(stg_plan_scatter_kernel, g, dim3(256), 0, st, pa);
+        a.perm = ctx->perm;
+    }
     a.actions = actions; a.K = K; a.out_every = out_every ? 1 : 0; a.autoreset = autoreset ? 1 : 0;
     a.obs = obs; a.reward = reward; a.reward64 = reward_f64; a.energy = energy; a.term = terminated; a.trunc = truncated; a.status = status;
     // the Simple solver only draws a thermal field when temperature > 0 (simple_solver.py:321,378)
     const bool thermal = ctx->cfg.thermal && ctx->cfg.temperature > 0;
     const bool multi = ctx->ncls > 1;
-    hipStream_t st = (hipStream_t)stream;
     switch (ctx->cfg.solver) {
-        case STG_SOLVER_RK4: dispatch_step<STG_SOLVER_RK4>(a, thermal, multi, act_f64, st); break;
-        case STG_SOLVER_EULER: dispatch_step<STG_SOLVER_EULER>(a, thermal, multi, act_f64, st); break;
-        default: dispatch_step<STG_SOLVER_RK45>(a, ctx->cfg.thermal != 0, multi, act_f64, st); break;
+        case STG_SOLVER_RK4: dispatch_step<STG_SOLVER_RK4>(a, thermal, multi, ctx->axis_z, act_f64, st); break;
+        case STG_SOLVER_EULER: dispatch_step<STG_SOLVER_EULER>(a, thermal, multi, ctx->axis_z, act_f64, st); break;
+        default: dispatch_step<STG_SOLVER_RK45>(a, ctx->cfg.thermal != 0, multi, false, act_f64, st); break;
     }
     HIP_TRY(hipGetLastError());
     return STG_OK;

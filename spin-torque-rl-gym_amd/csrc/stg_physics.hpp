@@ -146,7 +146,7 @@ struct NormalStream {
         const float sc = 1.0f / 16777216.0f;
         const float u0 = ((float)(next() >> 8) + 0.5f) * sc;
         const float u1 = ((float)(next() >> 8) + 0.5f) * sc;
-        const float r = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));   // sqrt(-2 ln u0)
+        const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));   // sqrt(-2 ln u0), raw v_sqrt_f32
         a = r * __builtin_amdgcn_cosf(u1);
         b = r * __builtin_amdgcn_sinf(u1);
     }
@@ -180,8 +180,31 @@ struct LlgsK {              // A6 constants
 //         = -geff [ p + m x (alpha p + kJ t) ],         t = m x e,  kJ = aJ / (-geff)
 // 31 fp64 instructions (T = 0 K) instead of 42 for the literal form; every intermediate stays at or below the
 // magnitude of the reference's own intermediates, so overflow happens at the same sub-step.
-template <bool THERMAL>
+template <bool THERMAL, bool AXIS_Z>
 __device__ __forceinline__ V3 simple_rhs(const V3& m, const SimpleK& k, double kJ, const V3& z) {
+    if (AXIS_Z) {
+        // easy axis = +z exactly (every factory default, device_factory.py:129-172): t = (my, -mx, 0), H = (0, 0, hz),
+        // so the products with the axis' zero components drop out -- 14 fp64 instructions at T = 0 K.  (They only
+        // differ from the general form when a factor is already inf/NaN, where both forms end non-finite.)
+        const double hz = __builtin_fma(k.hk, m.z, -k.ms * m.z);
+        V3 p;
+        if (THERMAL) {
+            const V3 h{k.hs * z.x, k.hs * z.y, __builtin_fma(k.hs, z.z, hz)};
+            p = cross(m, h);
+        } else {
+            p = V3{m.y * hz, -(m.x * hz), 0.0};
+        }
+        const double wx = __builtin_fma(k.alpha, p.x, kJ * m.y), wy = __builtin_fma(k.alpha, p.y, -(kJ * m.x));
+        V3 r;
+        if (THERMAL) {
+            const double wz = k.alpha * p.z;
+            r = V3{__builtin_fma(m.y, wz, __builtin_fma(-m.z, wy, p.x)), __builtin_fma(m.z, wx, __builtin_fma(-m.x, wz, p.y)),
+                   __builtin_fma(m.x, wy, __builtin_fma(-m.y, wx, p.z))};
+        } else {
+            r = V3{__builtin_fma(-m.z, wy, p.x), __builtin_fma(m.z, wx, p.y), __builtin_fma(m.x, wy, -(m.y * wx))};
+        }
+        return V3{-k.geff * r.x, -k.geff * r.y, -k.geff * r.z};
+    }
     const V3 t = cross(m, k.e);
     const double c = k.hk * dot(m, k.e);
     const double d = -k.ms * m.z;
@@ -251,7 +274,7 @@ struct Recorder {
 };
 
 // A3 + A4 + A5: RobustLLGSSolver.solve -> SimpleLLGSSolver.solve, METHOD 0 = rk4, 1 = euler.
-template <int METHOD, bool THERMAL, bool RECORD>
+template <int METHOD, bool THERMAL, bool RECORD, bool AXIS_Z>
 __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double T, const SimpleK& k, double pol,
                                                  double msv, bool class_valid, double temperature, double max_step,
                                                  const RngKey& rk, const Recorder& rec) {
@@ -291,20 +314,20 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
         if (METHOD == 1) {
             V3 z0 = zero;
             if (THERMAL) z0 = (i & 1) ? ns.draw3_odd() : ns.draw3_even();
-            const V3 f = simple_rhs<THERMAL>(m, k, kJ, z0);
+            const V3 f = simple_rhs<THERMAL, AXIS_Z>(m, k, kJ, z0);
             mn = V3{m.x + dt * f.x, m.y + dt * f.y, m.z + dt * f.z};      // simple_solver.py:275-276
         } else {
             V3 z0 = zero, z1 = zero, z2 = zero, z3 = zero;
             if (THERMAL) {   // 12 normals = 6 Box-Muller pairs per sub-step
                 z0 = ns.draw3_even(); z1 = ns.draw3_odd(); z2 = ns.draw3_even(); z3 = ns.draw3_odd();
             }
-            const V3 f1 = simple_rhs<THERMAL>(m, k, kJ, z0);
+            const V3 f1 = simple_rhs<THERMAL, AXIS_Z>(m, k, kJ, z0);
             const V3 y2{m.x + half_dt * f1.x, m.y + half_dt * f1.y, m.z + half_dt * f1.z};
-            const V3 f2 = simple_rhs<THERMAL>(y2, k, kJ2, z1);
+            const V3 f2 = simple_rhs<THERMAL, AXIS_Z>(y2, k, kJ2, z1);
             const V3 y3{m.x + half_dt * f2.x, m.y + half_dt * f2.y, m.z + half_dt * f2.z};
-            const V3 f3 = simple_rhs<THERMAL>(y3, k, kJ2, z2);
+            const V3 f3 = simple_rhs<THERMAL, AXIS_Z>(y3, k, kJ2, z2);
             const V3 y4{m.x + dt * f3.x, m.y + dt * f3.y, m.z + dt * f3.z};
-            const V3 f4 = simple_rhs<THERMAL>(y4, k, kJ4, z3);
+            const V3 f4 = simple_rhs<THERMAL, AXIS_Z>(y4, k, kJ4, z3);
             // m + (k1 + 2 k2 + 2 k3 + k4)/6 with k = dt*f                  simple_solver.py:290-295
             mn = V3{m.x + sixth_dt * ((f1.x + 2.0 * f2.x) + (2.0 * f3.x + f4.x)),
                     m.y + sixth_dt * ((f1.y + 2.0 * f2.y) + (2.0 * f3.y + f4.y)),

@@ -24,7 +24,7 @@ class StgConfig(C.Structure):
         ("n_targets", C.c_int32), ("max_current", C.c_double), ("max_duration", C.c_double),
         ("success_threshold", C.c_double), ("energy_penalty_weight", C.c_double),
         ("targets", (C.c_double * 3) * STG_MAX_TARGETS), ("seed", C.c_uint64), ("max_attempts", C.c_int64),
-        ("skip_done", C.c_int32), ("reserved", C.c_int32),
+        ("skip_done", C.c_int32), ("lane_sort", C.c_int32),
     ]
 
 

@@ -34,6 +34,7 @@ class EnvConfig:
     seed: int = 0
     max_attempts: int = 2_000_000
     skip_done: bool = False
+    lane_sort: Optional[bool] = None          # duration-sorted lane schedule: None = automatic, True/False = force
 
     def to_abi(self) -> "_lib.StgConfig":
         if self.solver not in _lib.SOLVERS:
@@ -55,6 +56,7 @@ class EnvConfig:
         c.seed = int(self.seed) & 0xFFFFFFFFFFFFFFFF
         c.max_attempts = int(self.max_attempts)
         c.skip_done = int(bool(self.skip_done))
+        c.lane_sort = 0 if self.lane_sort is None else (1 if self.lane_sort else -1)
         return c
 
 
