@@ -212,18 +212,33 @@ class OracleBackend:
         mf = np.zeros((3, n))
         npts = np.zeros(n, dtype=np.int32)
         succ = np.zeros(n, dtype=np.uint8)
+        tt = np.zeros((max(traj_cap, 1), n))
+        tm = np.zeros((max(traj_cap, 1), 3, n))
+        te = np.zeros((max(traj_cap, 1), n))
         for i in range(n):
             p = self._p(i)
             if self.cfg.solver == "rk45":
-                r = oracle.llgs_solve(m0[:, i], T[i], p, self.ocfg, J[i], self.env_id0 + i, env_step, cap=1)
+                r = oracle.llgs_solve(m0[:, i], T[i], p, self.ocfg, J[i], self.env_id0 + i, env_step, cap=max(traj_cap, 1))
                 mf[:, i] = r["m_final"] if r["success"] else m0[:, i]
                 npts[i] = r["n_points"] - 1
+                k = min(len(r["t"]), traj_cap)
+                tt[:k, i], tm[:k, :, i], te[:k, i] = r["t"][:k], r["m"][:k], r["energy"][:k]
             else:
-                r = oracle.simple_solve(m0[:, i], T[i], p, self.ocfg, J[i], self.env_id0 + i, env_step)
+                r = oracle.simple_solve(m0[:, i], T[i], p, self.ocfg, J[i], self.env_id0 + i, env_step, want_traj=traj_cap > 0)
                 mf[:, i] = r["m_final"]
                 npts[i] = r["n_steps"]
+                if traj_cap > 0 and "m" in r:
+                    k = min(len(r["m"]), traj_cap)
+                    tm[:k, :, i] = r["m"][:k]
+                    dt = T[i] / max(r["n_steps"], 1)
+                    tt[:k, i] = np.arange(k) * dt
+                    if k == r["n_steps"] + 1:
+                        tt[k - 1, i] = T[i]
             succ[i] = r["success"]
-        return dict(m_final=torch.from_numpy(mf), n_points=torch.from_numpy(npts), success=torch.from_numpy(succ))
+        out = dict(m_final=torch.from_numpy(mf), n_points=torch.from_numpy(npts), success=torch.from_numpy(succ))
+        if traj_cap > 0:
+            out.update(t=torch.from_numpy(tt), m=torch.from_numpy(tm), energy=torch.from_numpy(te) if want_energy else None)
+        return out
 
 
 def make_states(n, m, target):

@@ -395,3 +395,38 @@ def test_state_dict_roundtrip(stg):
     o2, r2, *_ = e2.step(a)
     assert torch.equal(o1, o2) and torch.equal(r1, r2)
     e1.close(); e2.close()
+
+
+def test_solver_facades_on_gpu(stg, golden):
+    """Reference-shaped solver classes (physics.py) on the HIP path: RobustLLGSSolver / LLGSSolver result dicts."""
+    from spin_torque_gym_amd.physics import LLGSSolver, RobustLLGSSolver
+    g1, g4 = golden("G1_simple_rk4_relax"), golden("G4_llgs_rk45_relax")
+    params = stt_default_params()
+    rs = RobustLLGSSolver(method="rk4", rtol=1e-3, atol=1e-6, timeout=2.0, max_retries=2, fallback_method="euler")
+    r = rs.solve(g1["m0"][0], (0, 1e-9), params, lambda t: 0.0, lambda t: np.zeros(3), False, 300.0)
+    assert r["success"] and np.abs(r["m"] - g1["traj0_m"]).max() <= TOL_RK4
+    bad = rs.solve(g1["m0"][0], (0, 1e-9), params, lambda t: 1e6, None, False, 300.0)
+    assert bad["success"] is False and bad.get("is_fallback")
+    ls = LLGSSolver()
+    c = g4["cases"][1]
+    r = ls.solve(c[:3], (0, c[3]), params, lambda t: 0.0, None, thermal_noise=False)
+    assert r["success"] and len(r["t"]) == len(g4["t_1"]) and np.abs(r["m"] - g4["m_1"]).max() <= TOL_RK45
+    st = ls.find_stable_states(params, n_trials=64, relax_time=2e-9, threshold=0.5, seed=0)
+    assert 1 <= len(st) <= 2 and np.all(np.abs(np.abs(st[:, 2]) - 1.0) < 1e-2)      # relaxes to +-z
+
+
+def test_float64_actions_match_reference_semantics(stg):
+    """A float64 action array is clamped in float64 (monitoring.py:304-313 works in the array's dtype)."""
+    n = 64
+    kw = dict(device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=False, seed=2)
+    e32 = stg.SpinTorqueVecEnv(n, **kw); e64 = stg.SpinTorqueVecEnv(n, **kw)
+    e32.reset(seed=1); e64.reset(seed=1)
+    a = torch.zeros((n, 2), dtype=torch.float64); a[:, 0] = 1.5e6; a[:, 1] = 1e-12      # 1e-12 is exact only in float64
+    o64, *_ = e64.step(a)
+    o32, *_ = e32.step(a.float())
+    # float32(1e-12) < 1e-12 -> clipped up to exactly 1e-12 in both; identical physics, identical outputs
+    assert torch.equal(o32, o64)
+    a[:, 1] = 3.3e-10                                   # not representable in float32: the two runs see different T
+    o64, *_ = e64.step(a); o32, *_ = e32.step(a.float())
+    assert not torch.equal(o32[:, :3], o64[:, :3]) and torch.allclose(o32[:, :3], o64[:, :3], atol=1e-5)
+    e32.close(); e64.close()
