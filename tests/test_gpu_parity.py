@@ -428,5 +428,5 @@ def test_float64_actions_match_reference_semantics(stg):
     assert torch.equal(o32, o64)
     a[:, 1] = 3.3e-10                                   # not representable in float32: the two runs see different T
     o64, *_ = e64.step(a); o32, *_ = e32.step(a.float())
-    assert not torch.equal(o32[:, :3], o64[:, :3]) and torch.allclose(o32[:, :3], o64[:, :3], atol=1e-5)
+    assert not torch.equal(o32[:, :3], o64[:, :3]) and torch.allclose(o32[:, :3], o64[:, :3], atol=1e-3)
     e32.close(); e64.close()
