@@ -106,7 +106,7 @@ __device__ __forceinline__ SolveOut run_solver(const V3& m, double J, double T, 
         const LlgsK k = load_llgs(row);
         LlgsEnergyK ek{};
         if (RECORD) ek = load_energy(row);
-        return llgs_solve<THERMAL, RECORD>(m, J, T, k, row[C_BETA], row[C_BETAP], c.rtol, c.atol, c.max_step,
+        return llgs_solve<THERMAL, RECORD, AXIS_Z>(m, J, T, k, row[C_BETA], row[C_BETAP], c.rtol, c.atol, c.max_step,
                                            c.max_attempts, rk, rec, ek);
     }
     const SimpleK k = load_simple(row);
@@ -447,6 +447,7 @@ struct stg_ctx {
     uint16_t* key = nullptr;
     bool have_params = false, have_state = false;
     bool axis_z = false;              // every class has easy axis = +z exactly: the specialised Simple RHS applies
+    bool axis_z_llgs = false;         // every class has raw easy axis (0,0,rz) and demag (0,0,Nz): specialised LLGS RHS
 };
 
 static CfgView cfg_view(const stg_config& c) {
@@ -573,6 +574,11 @@ int stg_set_params(stg_ctx* ctx, const stg_device_params* table, int32_t n_class
     ctx->axis_z = true;
     for (int k = 0; k < n_classes; ++k)
         ctx->axis_z = ctx->axis_z && ctx->h_ctab[k][C_EX] == 0.0 && ctx->h_ctab[k][C_EY] == 0.0 && ctx->h_ctab[k][C_EZ] == 1.0;
+    ctx->axis_z_llgs = true;
+    for (int k = 0; k < n_classes; ++k) {
+        const double* r = ctx->h_ctab[k];
+        ctx->axis_z_llgs = ctx->axis_z_llgs && r[C_RX] == 0.0 && r[C_RY] == 0.0 && r[C_DX] == 0.0 && r[C_DY] == 0.0;
+    }
     ctx->cls = n_classes > 1 ? cls : nullptr;
     ctx->have_params = true;
     return STG_OK;
@@ -616,10 +622,10 @@ static void dispatch_step2(const StepArgs& a, bool thermal, bool multi, int act_
     if (thermal) { if (multi) launch_step<SOLVER, true, true, AXIS_Z>(a, act_f64, st); else launch_step<SOLVER, true, false, AXIS_Z>(a, act_f64, st); }
     else { if (multi) launch_step<SOLVER, false, true, AXIS_Z>(a, act_f64, st); else launch_step<SOLVER, false, false, AXIS_Z>(a, act_f64, st); }
 }
-// axis_z selects the easy-axis = +z specialisation of the Simple RHS (RK45 has no such variant)
+// axis_z selects the easy-axis = z specialisation of the RHS (Simple: e = +z; LLGS: raw axis and demag along z)
 template <int SOLVER>
 static void dispatch_step(const StepArgs& a, bool thermal, bool multi, bool axis_z, int act_f64, hipStream_t st) {
-    if (SOLVER != STG_SOLVER_RK45 && axis_z) dispatch_step2<SOLVER, true>(a, thermal, multi, act_f64, st);
+    if (axis_z) dispatch_step2<SOLVER, true>(a, thermal, multi, act_f64, st);
     else dispatch_step2<SOLVER, false>(a, thermal, multi, act_f64, st);
 }
 }  // extern "C++"
@@ -664,7 +670,7 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
     switch (ctx->cfg.solver) {
         case STG_SOLVER_RK4: dispatch_step<STG_SOLVER_RK4>(a, thermal, multi, ctx->axis_z, act_f64, st); break;
         case STG_SOLVER_EULER: dispatch_step<STG_SOLVER_EULER>(a, thermal, multi, ctx->axis_z, act_f64, st); break;
-        default: dispatch_step<STG_SOLVER_RK45>(a, ctx->cfg.thermal != 0, multi, false, act_f64, st); break;
+        default: dispatch_step<STG_SOLVER_RK45>(a, ctx->cfg.thermal != 0, multi, ctx->axis_z_llgs, act_f64, st); break;
     }
     HIP_TRY(hipGetLastError());
     return STG_OK;

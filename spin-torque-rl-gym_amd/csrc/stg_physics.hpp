@@ -86,13 +86,19 @@ __device__ __forceinline__ double rsqrt_fast(double s) {
     return __builtin_fma(y * e, __builtin_fma(0.375, e, 0.5), y);
 }
 
-// err^(-1/5) for err in (5.9e-6, 1845): fp32 transcendental seed + one third-order Newton step on y^-5 = err (~1 ulp).
-// Stands in for the libm pow of SciPy's step-size controller (rk.py:158-168).
-__device__ __forceinline__ double inv_fifth_root(double err) {
-    const double y = (double)__builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf((float)err));
-    const double y2 = y * y, y4 = y2 * y2;
-    const double e = __builtin_fma(-err, y4 * y, 1.0);
-    return __builtin_fma(y * e, __builtin_fma(0.12, e, 0.2), y);
+// 1/x: hardware seed (v_rcp_f64) + one Newton step, ~1 ulp.
+__device__ __forceinline__ double rcp_fast(double x) {
+    const double y = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
+}
+
+// e2^(-1/10) for e2 = err^2 in (3.5e-11, 3.4e6), i.e. err^(-1/5): fp32 transcendental seed + one third-order Newton step
+// on y^-10 = e2 (~1 ulp).  Stands in for the libm pow of SciPy's step-size controller (rk.py:158-168).
+__device__ __forceinline__ double inv_tenth_root(double e2) {
+    const double y = (double)__builtin_amdgcn_exp2f(-0.1f * __builtin_amdgcn_logf((float)e2));
+    const double y2 = y * y, y4 = y2 * y2, y8 = y4 * y4;
+    const double e = __builtin_fma(-e2, y8 * y2, 1.0);                // e = 1 - e2 y^10 = -(10 d + 45 d^2), y = y*(1+d)
+    return __builtin_fma(y * e, __builtin_fma(0.055, e, 0.1), y);     // y (1 + e/10 + 11 e^2/200)
 }
 
 __device__ __forceinline__ V3 cross(const V3& a, const V3& b) {
@@ -346,7 +352,10 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
 }
 
 // A6: LLGSSolver.solve::llgs_rhs.  bJ = beta*J, bpJ = beta'*J (0 when |J| < 1e-12 or the pulse is over).
-template <bool THERMAL>
+// AXIS_Z: raw easy axis = (0,0,rz) and demag factors = (0,0,Nz) (every factory default): H = hex*m + (0,0,g) (+ hs z).
+// The exchange placeholder hex*m (llgs_solver.py:205-209) is parallel to m, so it cancels in m x H up to a rounding
+// residue of ~1e-16 * hex (hex ~ 4e-6 A/m against H_k ~ 2.4e6 A/m) and is dropped there; the general form keeps it.
+template <bool THERMAL, bool AXIS_Z>
 __device__ __forceinline__ V3 llgs_rhs(const V3& y, const LlgsK& k, double bJ, double bpJ, const V3& z) {
     const double ss = dot(y, y);
     V3 m{0.0, 0.0, 1.0};
@@ -354,19 +363,31 @@ __device__ __forceinline__ V3 llgs_rhs(const V3& y, const LlgsK& k, double bJ, d
         const double inv = rsqrt_fast(ss);
         m = V3{y.x * inv, y.y * inv, y.z * inv};
     }
-    const double c = k.hk * dot(m, k.r);
-    V3 h{(c * k.r.x + k.d.x * m.x) + k.hex * m.x, (c * k.r.y + k.d.y * m.y) + k.hex * m.y,
-         (c * k.r.z + k.d.z * m.z) + k.hex * m.z};
-    if (THERMAL) h = V3{h.x + k.hs * z.x, h.y + k.hs * z.y, h.z + k.hs * z.z};            // llgs_solver.py:111-113
-    const V3 mxh = cross(m, h);
+    V3 mxh;
+    if (AXIS_Z) {
+        const double g = __builtin_fma(k.hk * k.r.z, k.r.z * m.z, k.d.z * m.z);   // hk (m.r) r_z - ms N_z m_z
+        if (THERMAL) {
+            const V3 h{k.hs * z.x, k.hs * z.y, __builtin_fma(k.hs, z.z, g)};
+            mxh = cross(m, h);
+        } else {
+            mxh = V3{m.y * g, -(m.x * g), 0.0};
+        }
+    } else {
+        const double c = k.hk * dot(m, k.r);
+        V3 h{(c * k.r.x + k.d.x * m.x) + k.hex * m.x, (c * k.r.y + k.d.y * m.y) + k.hex * m.y,
+             (c * k.r.z + k.d.z * m.z) + k.hex * m.z};
+        if (THERMAL) h = V3{h.x + k.hs * z.x, h.y + k.hs * z.y, h.z + k.hs * z.z};        // llgs_solver.py:111-113
+        mxh = cross(m, h);
+    }
     V3 dm{-k.gamma * mxh.x, -k.gamma * mxh.y, -k.gamma * mxh.z};
-    const V3 mxdm = cross(m, dm);
+    V3 mxdm;
+    if (AXIS_Z && !THERMAL) mxdm = V3{-(m.z * dm.y), m.z * dm.x, __builtin_fma(m.x, dm.y, -(m.y * dm.x))};   // dm.z = 0
+    else mxdm = cross(m, dm);
     dm = V3{dm.x + k.alpha * mxdm.x, dm.y + k.alpha * mxdm.y, dm.z + k.alpha * mxdm.z};   // llgs_solver.py:123
     // p_hat = z: m x z = (my, -mx, 0); m x (m x z) = (mx mz, my mz, -(mx^2 + my^2))        llgs_solver.py:226-235
-    const V3 mxp{m.y, -m.x, 0.0};
-    const V3 mxmxp = cross(m, mxp);
-    return V3{dm.x + (bJ * mxmxp.x + bpJ * mxp.x), dm.y + (bJ * mxmxp.y + bpJ * mxp.y),
-              dm.z + (bJ * mxmxp.z + bpJ * mxp.z)};
+    const double uz = -__builtin_fma(m.x, m.x, m.y * m.y);
+    return V3{__builtin_fma(bJ, m.x * m.z, __builtin_fma(bpJ, m.y, dm.x)), __builtin_fma(bJ, m.y * m.z, __builtin_fma(-bpJ, m.x, dm.y)),
+              __builtin_fma(bJ, uz, dm.z)};
 }
 
 struct LlgsEnergyK {
@@ -382,7 +403,7 @@ __device__ __forceinline__ double llgs_energy(const V3& m, const LlgsEnergyK& k)
 __device__ __forceinline__ double rms3(const V3& a) { return sqrt(dot(a, a)) / 1.7320508075688772; }   // common.py:63-65
 
 // A7 (+A8 when RECORD): scipy solve_ivp(RK45) as LLGSSolver.solve drives it.
-template <bool THERMAL, bool RECORD>
+template <bool THERMAL, bool RECORD, bool AXIS_Z>
 __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T, const LlgsK& k, double beta,
                                                double betap, double rtol, double atol, double max_step,
                                                int64_t max_attempts, const RngKey& rk, const Recorder& rec,
@@ -408,7 +429,7 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
         const bool on = t <= T;
         V3 z = zero;
         if (THERMAL) z = even ? ns.draw3_even() : ns.draw3_odd();
-        return llgs_rhs<THERMAL>(y, k, on ? bJ : 0.0, on ? bpJ : 0.0, z);
+        return llgs_rhs<THERMAL, AXIS_Z>(y, k, on ? bJ : 0.0, on ? bpJ : 0.0, z);
     };
     const double n0 = rsqrt_fast(dot(m0, m0));                              // llgs_solver.py:76
     V3 y{m0.x * n0, m0.y * n0, m0.z * n0};
@@ -479,10 +500,14 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
                     (k1.z * E1 + k3.z * E3 + k4.z * E4 + k5.z * E5 + k6.z * E6 + f_new.z * E7) * h};
         const V3 sc{atol + fmax(fabs(y.x), fabs(y_new.x)) * rtol, atol + fmax(fabs(y.y), fabs(y_new.y)) * rtol,
                     atol + fmax(fabs(y.z), fabs(y_new.z)) * rtol};
-        const double err = rms3(V3{ev.x / sc.x, ev.y / sc.y, ev.z / sc.z});
+        // error_norm = rms(ev / scale) (rk.py:104-109); the controller only needs err < 1 and err^-0.2, so the kernel
+        // carries err^2 (no sqrt) and divides by reciprocal-multiply (v_rcp_f64 + one Newton step, ~1 ulp)
+        const V3 q{ev.x * rcp_fast(sc.x), ev.y * rcp_fast(sc.y), ev.z * rcp_fast(sc.z)};
+        const double err2 = dot(q, q) * (1.0 / 3.0);
+        const double err = err2;      // compared against squared thresholds below
         // 0.9 * err^-0.2 saturates at MAX_FACTOR = 10 for err <= 0.09^5 and at MIN_FACTOR = 0.2 for err >= 4.5^5
         if (err < 1.0) {
-            double factor = (err <= 5.9049e-6) ? 10.0 : fmin(10.0, 0.9 * inv_fifth_root(err));   // also err == 0
+            double factor = (err <= 3.486784401e-11) ? 10.0 : fmin(10.0, 0.9 * inv_tenth_root(err));   // also err == 0
             if (rejected) factor = fmin(1.0, factor);
             h_abs *= factor;
             // step accepted: advance, record, and do the next step()'s prologue
@@ -493,7 +518,7 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
             h_abs = h_abs > max_step ? max_step : (h_abs < min_step ? min_step : h_abs);
         } else {
             // NaN error norms land here too (nan < 1 is False), as in SciPy; fmax(0.2, NaN) = 0.2
-            const double g = (err >= 1845.28125) ? 0.2 : fmax(0.2, 0.9 * inv_fifth_root(err));
+            const double g = (err >= 3405062.8916015625) ? 0.2 : fmax(0.2, 0.9 * inv_tenth_root(err));
             h_abs *= g;
             rejected = true;
         }
