@@ -157,6 +157,30 @@ def roofline(meas, n_local, steps, solver, mixed=False):
                     "bytes_per_env_step": BYTES_PER_ENV_STEP_MIXED if mixed else BYTES_PER_ENV_STEP}}
 
 
+def usable_cores(omp_max):
+    """Host cores this process may really use: the affinity mask, capped by the cgroup CPU quota if there is one."""
+    n = omp_max
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(solver, thermal, seconds):
     """The oracle (CPU restatement, "port") on this box's host cores, same workload distribution, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -170,7 +194,7 @@ def cpu_baseline(solver, thermal, seconds):
     tgt = np.where(rng.integers(0, 2, (n, 1)) == 0, 1.0, -1.0) * np.array([[0.0, 0.0, 1.0]])
     p = (oracle.Params * 1)(oracle.make_params(stt_params(volume_for(solver))))
     c = oracle.make_config(solver=solver, thermal=bool(thermal), seed=1234)
-    threads = oracle.lib().stgo_max_threads()
+    threads = usable_cores(oracle.lib().stgo_max_threads())
     done_steps, t_used, batches = 0, 0.0, 0
     while t_used < seconds and batches < 64:
         st = make_states(n, m0, tgt)

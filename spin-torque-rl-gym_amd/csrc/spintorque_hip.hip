@@ -354,7 +354,9 @@ __global__ void stg_normals_kernel(uint64_t seed, int64_t env_id0, int64_t N, ui
 // The trip count of a lane is set by its pulse duration (RK4: n = T/dt sub-steps; RK45: attempts ~ T / 0.65 ps), which
 // the agent chooses per env: U[0.1, 1] ns gives a mean/max ratio of 0.55 inside a wavefront.  Three tiny kernels
 // (histogram in LDS -> scan -> scatter) build a permutation with equal-work envs adjacent; cost ~10 us per step.
-constexpr int PLAN_BUCKETS = 1024;
+constexpr int PLAN_BUCKETS = 256;     // 20 ps of pulse duration per bucket at the default 5 ns maximum
+constexpr int PLAN_THREADS = 1024;
+constexpr int PLAN_ITEMS = 4;         // envs per thread: 4096 envs per workgroup share one global atomic per bucket
 
 struct PlanArgs {
     const void* actions;      // [2][N] of the first fused step
@@ -363,7 +365,7 @@ struct PlanArgs {
     double max_current, max_duration;
     const uint8_t* done;      // with skip_done: finished envs go last (no work)
     int32_t skip_done;
-    uint16_t* key;
+    uint8_t* key;
     uint32_t *hist, *cursor, *perm;
 };
 
@@ -378,19 +380,22 @@ __device__ __forceinline__ int plan_key(const PlanArgs& a, int64_t i) {
     return (PLAN_BUCKETS - 2) - b;                             // descending work: long pulses are dispatched first
 }
 
-__global__ void __launch_bounds__(256) stg_plan_hist_kernel(const PlanArgs a) {
+__global__ void __launch_bounds__(PLAN_THREADS) stg_plan_hist_kernel(const PlanArgs a) {
     __shared__ uint32_t h[PLAN_BUCKETS];
-    for (int j = threadIdx.x; j < PLAN_BUCKETS; j += 256) h[j] = 0;
+    if (threadIdx.x < PLAN_BUCKETS) h[threadIdx.x] = 0;
     __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < a.N) {
-        const int k = plan_key(a, i);
-        a.key[i] = (uint16_t)k;
-        atomicAdd(&h[k], 1u);
+    const int64_t base = (int64_t)blockIdx.x * (PLAN_THREADS * PLAN_ITEMS);
+#pragma unroll
+    for (int r = 0; r < PLAN_ITEMS; ++r) {
+        const int64_t i = base + r * PLAN_THREADS + threadIdx.x;
+        if (i < a.N) {
+            const int k = plan_key(a, i);
+            a.key[i] = (uint8_t)k;
+            atomicAdd(&h[k], 1u);
+        }
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < PLAN_BUCKETS; j += 256)
-        if (h[j]) atomicAdd(&a.hist[j], h[j]);
+    if (threadIdx.x < PLAN_BUCKETS && h[threadIdx.x]) atomicAdd(&a.hist[threadIdx.x], h[threadIdx.x]);
 }
 
 __global__ void __launch_bounds__(PLAN_BUCKETS) stg_plan_scan_kernel(uint32_t* hist, uint32_t* cursor) {
@@ -409,11 +414,32 @@ __global__ void __launch_bounds__(PLAN_BUCKETS) stg_plan_scan_kernel(uint32_t* h
     hist[t] = 0;                                               // ready for the next step
 }
 
-__global__ void __launch_bounds__(256) stg_plan_scatter_kernel(const PlanArgs a) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.N) return;
-    const uint32_t pos = atomicAdd(&a.cursor[a.key[i]], 1u);
-    a.perm[pos] = (uint32_t)i;
+// Workgroup-aggregated scatter: ranks inside the workgroup come from LDS atomics, each workgroup reserves its range
+// of a bucket with ONE global atomic (per-address contention N/4096 instead of N/buckets).
+__global__ void __launch_bounds__(PLAN_THREADS) stg_plan_scatter_kernel(const PlanArgs a) {
+    __shared__ uint32_t cnt[PLAN_BUCKETS], start[PLAN_BUCKETS];
+    if (threadIdx.x < PLAN_BUCKETS) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * (PLAN_THREADS * PLAN_ITEMS);
+    uint32_t rank[PLAN_ITEMS];
+    int key[PLAN_ITEMS];
+#pragma unroll
+    for (int r = 0; r < PLAN_ITEMS; ++r) {
+        const int64_t i = base + r * PLAN_THREADS + threadIdx.x;
+        key[r] = -1;
+        if (i < a.N) {
+            key[r] = a.key[i];
+            rank[r] = atomicAdd(&cnt[key[r]], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < PLAN_BUCKETS && cnt[threadIdx.x]) start[threadIdx.x] = atomicAdd(&a.cursor[threadIdx.x], cnt[threadIdx.x]);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PLAN_ITEMS; ++r) {
+        const int64_t i = base + r * PLAN_THREADS + threadIdx.x;
+        if (key[r] >= 0) a.perm[start[key[r]] + rank[r]] = (uint32_t)i;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -444,7 +470,7 @@ struct stg_ctx {
     const uint8_t* cls = nullptr;     // caller-owned device pointer
     unsigned long long* counters = nullptr;
     uint32_t *perm = nullptr, *hist = nullptr, *cursor = nullptr;
-    uint16_t* key = nullptr;
+    uint8_t* key = nullptr;
     bool have_params = false, have_state = false;
     bool axis_z = false;              // every class has easy axis = +z exactly: the specialised Simple RHS applies
     bool axis_z_llgs = false;         // every class has raw easy axis (0,0,rz) and demag (0,0,Nz): specialised LLGS RHS
@@ -495,8 +521,7 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
     const size_t N = (size_t)n_envs;
     const size_t r8 = al(N * 8), r4 = al(N * 4), r1 = al(N);
-    const size_t r2 = al(N * 2);
-    const size_t total = 7 * r8 + 3 * r4 + r1 + r2 + al(sizeof(double) * STG_MAX_CLASSES * C_COUNT) + 256 +
+    const size_t total = 7 * r8 + 3 * r4 + 2 * r1 + al(sizeof(double) * STG_MAX_CLASSES * C_COUNT) + 256 +
                          2 * al(sizeof(uint32_t) * PLAN_BUCKETS);
     hipError_t e = hipMalloc(&c->slab, total);
     if (e != hipSuccess) { delete c; return fail(STG_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
@@ -511,7 +536,7 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     c->ctab = (double*)p; p += al(sizeof(double) * STG_MAX_CLASSES * C_COUNT);
     c->counters = (unsigned long long*)p; p += 256;
     c->perm = (uint32_t*)p; p += r4;
-    c->key = (uint16_t*)p; p += r2;
+    c->key = (uint8_t*)p; p += r1;
     c->hist = (uint32_t*)p; p += al(sizeof(uint32_t) * PLAN_BUCKETS);
     c->cursor = (uint32_t*)p;
     *out = c;
@@ -656,10 +681,11 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
         pa.max_current = ctx->cfg.max_current; pa.max_duration = ctx->cfg.max_duration;
         pa.done = ctx->s.done; pa.skip_done = (ctx->cfg.skip_done && !autoreset) ? 1 : 0;
         pa.key = ctx->key; pa.hist = ctx->hist; pa.cursor = ctx->cursor; pa.perm = ctx->perm;
-        const dim3 g((unsigned)((ctx->N + 255) / 256));
-        hipLaunchKernelGGL(stg_plan_hist_kernel, g, dim3(256), 0, st, pa);
+        const int64_t per_wg = (int64_t)PLAN_THREADS * PLAN_ITEMS;
+        const dim3 g((unsigned)((ctx->N + per_wg - 1) / per_wg));
+        hipLaunchKernelGGL(stg_plan_hist_kernel, g, dim3(PLAN_THREADS), 0, st, pa);
         hipLaunchKernelGGL(stg_plan_scan_kernel, dim3(1), dim3(PLAN_BUCKETS), 0, st, ctx->hist, ctx->cursor);
-        hipLaunchKernelGGL(stg_plan_scatter_kernel, g, dim3(256), 0, st, pa);
+        hipLaunchKernelGGL(stg_plan_scatter_kernel, g, dim3(PLAN_THREADS), 0, st, pa);
         a.perm = ctx->perm;
     }
     a.actions = actions; a.K = K; a.out_every = out_every ? 1 : 0; a.autoreset = autoreset ? 1 : 0;
