@@ -430,3 +430,28 @@ def test_float64_actions_match_reference_semantics(stg):
     o64, *_ = e64.step(a); o32, *_ = e32.step(a.float())
     assert not torch.equal(o32[:, :3], o64[:, :3]) and torch.allclose(o32[:, :3], o64[:, :3], atol=1e-3)
     e32.close(); e64.close()
+
+
+def test_g10_thermal_on_vs_reference(stg, golden):
+    """Thermal field ON, HIP path against the reference's recorded samples (statistical; see test_oracle_golden)."""
+    from test_oracle_golden import check_thermal_diffusion
+    g = golden("G10_thermal_diffusion")
+    m0 = g["rk4_m0"]
+    table = [_flat(stg, stt_default_params(volume=float(v))) for v in sorted(set(g["wellcond"][:, 0]))]
+    vols = sorted(set(g["wellcond"][:, 0]))
+    rows = g["wellcond"]
+    b = _backend(stg, len(rows), table, torch.tensor([vols.index(v) for v in rows[:, 0]], dtype=torch.uint8), solver="rk4",
+                 include_thermal_fluctuations=True, seed=5)
+    out = b.solve(torch.tensor(np.tile(m0, (len(rows), 1)).T.copy()), torch.tensor(rows[:, 1].copy()), torch.tensor(rows[:, 2].copy()))
+    assert np.abs(out["m_final"].cpu().numpy().T - rows[:, 6:9]).max() < 1e-7
+    assert np.array_equal(out["success"].cpu().numpy().astype(bool), rows[:, 9].astype(bool))
+    b.close()
+
+    def solve_many(solver, m0, T, vol, n):
+        b = _backend(stg, n, [_flat(stg, stt_default_params(volume=vol))], solver=solver, include_thermal_fluctuations=True, seed=99)
+        out = b.solve(torch.tensor(np.tile(m0, (n, 1)).T.copy()), torch.zeros(n, dtype=torch.float64),
+                      torch.full((n,), T, dtype=torch.float64))
+        res = out["m_final"].cpu().numpy().T.copy(), out["n_points"].cpu().numpy().copy()
+        b.close()
+        return res
+    check_thermal_diffusion(g, solve_many, 65536, 16384, "hip")

@@ -200,3 +200,55 @@ def test_philox_known_answer(oracle_mod):
     assert ph([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     assert ph([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def _diffusion_stats(samples, det):
+    d = samples - det
+    return d.mean(axis=0), np.sqrt((d ** 2).sum(axis=1).mean())
+
+
+def check_thermal_diffusion(g, solve_many, n_rk4, n_rk45, label):
+    """Shared by the CPU (oracle) and GPU (HIP) tests: statistical parity of the Langevin diffusion with the reference.
+    solve_many(solver, m0, T, volume, n) -> (final m [n,3], accepted points [n])."""
+    for solver, n in (("rk4", n_rk4), ("rk45", n_rk45)):
+        ref, det = g[f"{solver}_samples"], g[f"{solver}_deterministic"]
+        ours, npts = solve_many(solver, g[f"{solver}_m0"], float(g[f"{solver}_T"]), float(g[f"{solver}_volume"]), n)
+        mean_ref, rms_ref = _diffusion_stats(ref, det)
+        mean_our, rms_our = _diffusion_stats(ours, det)
+        se = rms_ref / np.sqrt(len(ref))                      # standard error of the reference's sample mean
+        assert np.all(np.abs(mean_our - mean_ref) < 5 * se), (label, solver, mean_our, mean_ref, se)
+        tol = 0.12 if solver == "rk4" else 0.2                # ~4 sigma of the rms estimate from 600 / 200 samples
+        assert abs(rms_our / rms_ref - 1.0) < tol, (label, solver, rms_our, rms_ref)
+        assert np.all(np.abs(np.linalg.norm(ours, axis=1) - 1) < 1e-12)
+        if solver == "rk45":                                  # the noise also drives the step-size controller
+            assert abs(np.mean(npts) / np.mean(g["rk45_npts"] - 1) - 1.0) < 0.05, (np.mean(npts), np.mean(g["rk45_npts"]))
+        print(f"{label} {solver}: rms ours {rms_our:.3e} ref {rms_ref:.3e}")
+
+
+def test_g10_thermal_on_vs_reference(golden, oracle_mod):
+    """Thermal field ON against the reference.  Well-conditioned regimes: the thermal-on result equals the reference's
+    (whose own thermal-on and thermal-off results agree to ~1e-10); V = 1e-30: diffusion statistics match."""
+    o = oracle_mod
+    g = golden("G10_thermal_diffusion")
+    m0 = g["rk4_m0"]
+    for vol, J, T, *rest in g["wellcond"]:
+        off_ref, on_ref, ok = np.array(rest[:3]), np.array(rest[3:6]), bool(rest[6])
+        assert np.abs(off_ref - on_ref).max() < 1e-7          # the reference itself: noise is (nearly) invisible here
+        p = o.make_params(stt_default_params(volume=vol))
+        r = o.simple_solve(m0, T, p, o.make_config("rk4", thermal=True, seed=5), J, env_id=3)
+        assert r["success"] == ok and np.abs(r["m_final"] - on_ref).max() < 1e-7
+
+    def solve_many(solver, m0, T, vol, n):
+        p = o.make_params(stt_default_params(volume=vol))
+        c = o.make_config(solver, thermal=True, seed=99)
+        out, npts = [], []
+        for e in range(n):
+            if solver == "rk4":
+                r = o.simple_solve(m0, T, p, c, 0.0, env_id=e)
+                npts.append(r["n_steps"])
+            else:
+                r = o.llgs_solve(m0, T, p, c, 0.0, env_id=e, cap=1)
+                npts.append(r["n_points"] - 1)
+            out.append(r["m_final"])
+        return np.array(out), np.array(npts)
+    check_thermal_diffusion(g, solve_many, 3000, 1500, "oracle")
