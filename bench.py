@@ -54,6 +54,8 @@ def parse_args():
     ap.add_argument("--also", type=int, default=1, help="run the secondary configurations too (N=1 only)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
+                    "rehearse the multi-rank code path on a single GPU)")
     return ap.parse_args()
 
 
@@ -123,7 +125,7 @@ def run_config(n_local, solver, thermal, steps, warmup, rank, world, device_inde
         backend.step(acts[warmup + k], autoreset=True)          # the step kernel, on torch's current stream
         ends[k].record()
         if world > 1:
-            env._gather()                                        # the single collective of a step
+            env._gather(unpack=False)                            # the single collective of a step
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -137,7 +139,7 @@ def run_config(n_local, solver, thermal, steps, warmup, rank, world, device_inde
 
 def _sharded_step(env, a):
     env.local.backend.step(a, autoreset=True)
-    env._gather()
+    env._gather(unpack=False)
 
 
 def roofline(meas, n_local, steps, solver, mixed=False):
@@ -222,8 +224,14 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        ndev = torch.cuda.device_count()
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % max(ndev, 1)          # rehearsal: several ranks may share one GPU
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(args.backend)
     n_local = args.envs_per_gpu
     meas = run_config(n_local, args.solver, args.thermal, args.steps, args.warmup, rank, world, local_rank)
     wall = torch.tensor([meas["wall_s"]], dtype=torch.float64, device=torch.device("cuda", local_rank))

@@ -32,7 +32,7 @@ class EnvConfig:
     energy_penalty_weight: float = 0.1
     target_states: Sequence[Sequence[float]] = field(default_factory=lambda: [[0.0, 0.0, 1.0], [0.0, 0.0, -1.0]])
     seed: int = 0
-    max_attempts: int = 2_000_000
+    max_attempts: int = 200_000               # RK45 attempts per solve before giving up (a 5 ns pulse needs ~10 000)
     skip_done: bool = False
     lane_sort: Optional[bool] = None          # duration-sorted lane schedule: None = automatic, True/False = force
 

@@ -49,9 +49,19 @@ class ShardedSpinTorqueVecEnv:
         dev = self.local.backend.packed.device
         self._gathered = torch.zeros(self.world * PACKED_BYTES_PER_ENV * self.n_local, dtype=torch.uint8, device=dev)
 
-    # the single collective of a step
-    def _gather(self):
-        dist.all_gather_into_tensor(self._gathered, self.local.backend.packed, group=self.group)
+    def _gather(self, unpack: bool = True):
+        """The single collective of a step.  unpack=False returns the raw [world * 54 * n_local] byte buffer (rank-major;
+        `unpack_step_buffer` gives typed views of each rank's slice) without the concatenation copies."""
+        packed = self.local.backend.packed
+        if packed.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal only (several ranks sharing one GPU): gloo moves host memory
+            host = torch.empty(self._gathered.shape, dtype=torch.uint8)
+            dist.all_gather_into_tensor(host, packed.cpu(), group=self.group)
+            self._gathered.copy_(host)
+        else:
+            dist.all_gather_into_tensor(self._gathered, packed, group=self.group)
+        if not unpack:
+            return self._gathered
         n = self.n_local
         parts = [unpack_step_buffer(self._gathered[r * PACKED_BYTES_PER_ENV * n:(r + 1) * PACKED_BYTES_PER_ENV * n], n)
                  for r in range(self.world)]

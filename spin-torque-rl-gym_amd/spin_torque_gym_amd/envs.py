@@ -93,7 +93,7 @@ class SpinTorqueVecEnv:
                  include_thermal_fluctuations: bool = True, success_threshold: float = 0.9,
                  energy_penalty_weight: float = 0.1, solver: str = "rk4", seed: Optional[int] = None,
                  autoreset: bool = False, skip_done: bool = False, device_index: int = 0, env_id0: int = 0,
-                 max_attempts: int = 2_000_000, backend=None):
+                 max_attempts: int = 200_000, backend=None):
         self.num_envs = int(num_envs)
         factory = DeviceFactory()
         types = [device_type] if isinstance(device_type, str) else list(device_type)
