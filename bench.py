@@ -54,6 +54,8 @@ def parse_args():
     ap.add_argument("--also", type=int, default=1, help="run the secondary configurations too (N=1 only)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--lane-sort", default="auto", choices=["auto", "on", "off"],
+                    help="duration-sorted lane schedule (auto: on for RK45 or > 2 waves per SIMD)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank code path on a single GPU)")
     return ap.parse_args()
@@ -79,11 +81,12 @@ def volume_for(solver):
     return 9.7e-6 if solver == "rk45" else 8.75e-11
 
 
-def run_config(n_local, solver, thermal, steps, warmup, rank, world, device_index, mixed=False, seed=1234):
+def run_config(n_local, solver, thermal, steps, warmup, rank, world, device_index, mixed=False, seed=1234, lane_sort=None):
     """Builds the env, runs warmup + timed steps, returns a dict of measurements (times are this rank's)."""
     import spin_torque_gym_amd as stg
     import torch.distributed as dist
-    kw = dict(include_thermal_fluctuations=bool(thermal), temperature=300.0, solver=solver, seed=seed, autoreset=True)
+    kw = dict(include_thermal_fluctuations=bool(thermal), temperature=300.0, solver=solver, seed=seed, autoreset=True,
+              lane_sort=lane_sort)
     if mixed:
         fac = stg.DeviceFactory()
         sot = fac.get_default_parameters("sot_mram"); sot.update(polarization=0.7, volume=volume_for(solver))
@@ -142,7 +145,20 @@ def _sharded_step(env, a):
     env._gather(unpack=False)
 
 
-def roofline(meas, n_local, steps, solver, mixed=False):
+def pmc_traffic(solver, thermal, n_local, sorted_schedule):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json), if that exact
+    configuration was profiled; None otherwise (counters cannot be read from inside this process)."""
+    try:
+        tab = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+    except (OSError, ValueError):
+        return None
+    for e in tab.get("entries", []):
+        if (e["solver"], bool(e["thermal"]), e["envs"], bool(e["lane_sort"])) == (solver, bool(thermal), n_local, bool(sorted_schedule)):
+            return int((e["fetch_kb"] + e["write_kb"]) * 1024)
+    return None
+
+
+def roofline(meas, n_local, steps, solver, mixed=False, thermal=None, sorted_schedule=None):
     flops_per_unit = FLOPS_PER_RK45_ATTEMPT if solver == "rk45" else FLOPS_PER_RK4_SUBSTEP
     launches = steps
     t = meas["kernel_ms_avg"] * 1e-3
@@ -151,7 +167,9 @@ def roofline(meas, n_local, steps, solver, mixed=False):
     tf = flops_per_launch / t / 1e12
     gbs = bytes_per_launch / t / 1e9
     return {"bound": "valu_fp64", "achieved": round(tf, 4), "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tf / PEAK_FP64_VALU_TFLOPS, 5), "traffic": None,
+            "frac": round(tf / PEAK_FP64_VALU_TFLOPS, 5),
+            "traffic": pmc_traffic(solver, thermal, n_local, sorted_schedule) if thermal is not None else None,
+            "algorithmic_bytes": bytes_per_launch,
             "kernel": "stg_step_kernel", "kernel_ms_avg": round(meas["kernel_ms_avg"], 4),
             "flops_per_work_unit": flops_per_unit,
             "work_units_per_env_step": round(meas["work_units"] / max(meas["env_steps"], 1), 2),
@@ -233,7 +251,8 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group(args.backend)
     n_local = args.envs_per_gpu
-    meas = run_config(n_local, args.solver, args.thermal, args.steps, args.warmup, rank, world, local_rank)
+    lane_sort = {"auto": None, "on": True, "off": False}[args.lane_sort]
+    meas = run_config(n_local, args.solver, args.thermal, args.steps, args.warmup, rank, world, local_rank, lane_sort=lane_sort)
     wall = torch.tensor([meas["wall_s"]], dtype=torch.float64, device=torch.device("cuda", local_rank))
     if world > 1:
         dist.all_reduce(wall, op=dist.ReduceOp.MAX)
@@ -248,7 +267,8 @@ def main():
                                f"full env.step, J~U[-2e6,2e6], pulse~U[0.1,1]ns f32, volume={volume_for(args.solver):g}, autoreset",
                    "envs_per_gpu": n_local, "global_envs": n_total, "solver": args.solver, "thermal": bool(args.thermal),
                    "parallelism": f"env-sharded x{world}, one all-gather of 54 B/env per step" if world > 1 else "single GPU"},
-        "roofline": roofline(meas, n_local, args.steps, args.solver),
+        "roofline": roofline(meas, n_local, args.steps, args.solver, thermal=args.thermal,
+                             sorted_schedule=(lane_sort if lane_sort is not None else (args.solver == "rk45" or n_local > 131072))),
     }
     if rank == 0 and world == 1 and args.also:
         also = []
