@@ -148,10 +148,13 @@ int stg_step(stg_ctx* ctx, const void* actions, int32_t act_f64, float* obs, flo
 
 /* K consecutive env steps in one launch (state stays in registers between steps).
  * actions [K][2][N]; outputs as stg_step with a leading [K] dimension; out_every = 1 writes every step's outputs,
- * 0 only the last step's (leading dimension 1).  autoreset != 0: an env whose episode ended at step k is reset on the
- * device (as stg_reset with NULL init_m/target) before step k+1. */
+ * 0 only the last step's (leading dimension 1).
+ * autoreset != 0 (same-step auto-reset, the usual GPU vector-env convention): an env whose episode ends at step k
+ * reports that step's reward / terminated / truncated, is then reset on the device (as stg_reset with NULL
+ * init_m/target, Philox key cfg.seed) and its obs row holds the NEW episode's first observation; final_obs
+ * (float[K or 1][12][N], may be NULL) receives the terminal observation of such envs (rows of other envs untouched). */
 int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64, int32_t out_every, int32_t autoreset,
-                  float* obs, float* reward, double* reward_f64, double* energy, uint8_t* terminated,
+                  float* obs, float* final_obs, float* reward, double* reward_f64, double* energy, uint8_t* terminated,
                   uint8_t* truncated, uint8_t* status, void* stream);
 
 /* state access for parity checks and checkpoint/resume; all pointers [dev], any may be NULL.

@@ -51,6 +51,7 @@ struct StepArgs {
     const uint32_t* perm;         // lane -> env (duration-sorted schedule) or nullptr
     unsigned long long* counters; // [4]: env-steps, integrator sub-steps/attempts, RHS evaluations, no-op steps
     float* obs;                   // [K or 1][12][N]
+    float* final_obs;             // [K or 1][12][N] or nullptr: terminal observation of envs auto-reset at that step
     float* reward;                // [K or 1][N]
     double *reward64, *energy;
     uint8_t *term, *trunc, *status;
@@ -192,10 +193,6 @@ __global__ void __launch_bounds__(64) stg_step_kernel(const StepArgs a) {
     unsigned long long c_steps = 0, c_sub = 0, c_noop = 0;
 
     for (int k = 0; k < a.K; ++k) {
-        if (a.autoreset && done) {
-            device_reset_draw(a.c.seed, env_id, rng, a.c, true, true, m, tgt);
-            etot = 0.0; step = 0; done = false;
-        }
         double J, T;
         parse_action<AT>(act[((int64_t)k * 2 + 0) * N + i], act[((int64_t)k * 2 + 1) * N + i], a.c.max_current,
                          a.c.max_duration, J, T);
@@ -239,6 +236,16 @@ __global__ void __launch_bounds__(64) stg_step_kernel(const StepArgs a) {
             st = so.ok ? (so.resets > 0 ? STG_STATUS_RESET : STG_STATUS_OK) : STG_STATUS_NOOP;
             c_steps += 1; c_sub += (unsigned long long)so.work; c_noop += so.ok ? 0 : 1;
             done = is_success || truncated;
+        }
+        // same-step auto-reset: the finished episode's reward/flags go out with this step, the state is redrawn on the
+        // device and the observation handed to the agent is the NEW episode's first one (the terminal observation goes
+        // to final_obs when the caller asked for it)
+        const bool do_reset = a.autoreset && done;
+        if (wr && do_reset && a.final_obs) write_obs(a.final_obs + ko * 12 * N, N, i, m, tgt, row, a.c, step, etot, J, T);
+        if (do_reset) {
+            device_reset_draw(a.c.seed, env_id, rng, a.c, true, true, m, tgt);
+            etot = 0.0; step = 0; done = false;
+            J = 0.0; T = 0.0;                       // last_action = zeros after reset (spin_torque_env.py:283)
         }
         if (wr) {
             write_obs(a.obs + ko * 12 * N, N, i, m, tgt, row, a.c, step, etot, J, T);
@@ -656,7 +663,7 @@ static void dispatch_step(const StepArgs& a, bool thermal, bool multi, bool axis
 }  // extern "C++"
 
 int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64, int32_t out_every, int32_t autoreset,
-                  float* obs, float* reward, double* reward_f64, double* energy, uint8_t* terminated,
+                  float* obs, float* final_obs, float* reward, double* reward_f64, double* energy, uint8_t* terminated,
                   uint8_t* truncated, uint8_t* status, void* stream) {
     if (!ctx) return fail(STG_E_INVALID, "ctx is NULL");
     if (!ctx->have_params || !ctx->have_state) return fail(STG_E_STATE, "stg_set_params and stg_reset must precede stg_step");
@@ -689,7 +696,7 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
         a.perm = ctx->perm;
     }
     a.actions = actions; a.K = K; a.out_every = out_every ? 1 : 0; a.autoreset = autoreset ? 1 : 0;
-    a.obs = obs; a.reward = reward; a.reward64 = reward_f64; a.energy = energy; a.term = terminated; a.trunc = truncated; a.status = status;
+    a.obs = obs; a.final_obs = final_obs; a.reward = reward; a.reward64 = reward_f64; a.energy = energy; a.term = terminated; a.trunc = truncated; a.status = status;
     // the Simple solver only draws a thermal field when temperature > 0 (simple_solver.py:321,378)
     const bool thermal = ctx->cfg.thermal && ctx->cfg.temperature > 0;
     const bool multi = ctx->ncls > 1;
@@ -704,8 +711,8 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
 
 int stg_step(stg_ctx* ctx, const void* actions, int32_t act_f64, float* obs, float* reward, double* reward_f64,
              double* energy, uint8_t* terminated, uint8_t* truncated, uint8_t* status, void* stream) {
-    return stg_step_many(ctx, 1, actions, act_f64, 1, 0, obs, reward, reward_f64, energy, terminated, truncated, status,
-                         stream);
+    return stg_step_many(ctx, 1, actions, act_f64, 1, 0, obs, nullptr, reward, reward_f64, energy, terminated, truncated,
+                         status, stream);
 }
 
 extern "C++" {

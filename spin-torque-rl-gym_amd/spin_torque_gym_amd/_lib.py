@@ -47,7 +47,7 @@ SYMBOLS = {
     "stg_set_params": (C.c_int, [_VP, C.POINTER(StgDeviceParams), C.c_int32, _VP]),
     "stg_reset": (C.c_int, [_VP, _VP, _VP, _VP, C.c_uint64, _VP, _VP]),
     "stg_step": (C.c_int, [_VP, _VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
-    "stg_step_many": (C.c_int, [_VP, C.c_int32, _VP, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "stg_step_many": (C.c_int, [_VP, C.c_int32, _VP, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "stg_get_state": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "stg_set_state": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "stg_get_counters": (C.c_int, [_VP, C.POINTER(C.c_uint64), C.c_int32]),

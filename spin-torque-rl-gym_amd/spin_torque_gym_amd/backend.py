@@ -105,6 +105,7 @@ class HipBackend:
         self.reward64 = torch.empty(n, dtype=torch.float64, device=dev)
         self.energy = torch.empty(n, dtype=torch.float64, device=dev)
         self.status = torch.empty(n, dtype=torch.uint8, device=dev)
+        self.final_obs = None                 # [12,N], allocated on the first auto-resetting step
 
     # -- plumbing -------------------------------------------------------------------------------
     def _stream(self):
@@ -164,7 +165,10 @@ class HipBackend:
         a = torch.as_tensor(actions)
         f64 = a.dtype == torch.float64
         a = self._dev(a, torch.float64 if f64 else torch.float32, (2, self.n))
+        if autoreset and self.final_obs is None:
+            self.final_obs = torch.zeros((12, self.n), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.stg_step_many(self._ctx, 1, _ptr(a), int(f64), 1, int(bool(autoreset)), _ptr(self.obs),
+                                          _ptr(self.final_obs) if autoreset else None,
                                           _ptr(self.reward), _ptr(self.reward64), _ptr(self.energy),
                                           _ptr(self.terminated), _ptr(self.truncated), _ptr(self.status),
                                           self._stream()))
@@ -186,8 +190,9 @@ class HipBackend:
         trunc = torch.empty((ko, n), dtype=torch.uint8, device=dev)
         status = torch.empty((ko, n), dtype=torch.uint8, device=dev)
         self.energy_many = torch.empty((ko, n), dtype=torch.float64, device=dev)
+        self.final_obs_many = torch.zeros((ko, 12, n), dtype=torch.float32, device=dev) if autoreset else None
         _lib.check(self.lib.stg_step_many(self._ctx, K, _ptr(a), int(f64), int(bool(out_every)), int(bool(autoreset)),
-                                          _ptr(obs), _ptr(reward), _ptr(reward64), _ptr(self.energy_many), _ptr(term),
+                                          _ptr(obs), _ptr(self.final_obs_many), _ptr(reward), _ptr(reward64), _ptr(self.energy_many), _ptr(term),
                                           _ptr(trunc), _ptr(status), self._stream()))
         self._keep = (a,)
         return obs, reward, reward64, term, trunc, status

@@ -153,8 +153,12 @@ class SpinTorqueVecEnv:
         if not actions_soa:
             a = a.t()
         obs, rew, rew64, term, trunc, status = self.backend.step(a, autoreset=self.autoreset)
-        energy = self.backend.energy
-        return obs.t(), rew, term.bool(), trunc.bool(), {"status": status, "reward_f64": rew64, "energy": energy}
+        info = {"status": status, "reward_f64": rew64, "energy": self.backend.energy}
+        if self.autoreset:
+            # same-step auto-reset: rows of `obs` whose episode just ended already hold the new episode's first
+            # observation; their terminal observation is in info["final_obs"] (valid where terminated | truncated)
+            info["final_obs"] = self.backend.final_obs.t()
+        return obs.t(), rew, term.bool(), trunc.bool(), info
 
     def step_many(self, actions, out_every: bool = True, actions_soa: bool = False):
         """K env steps in one launch.  actions [K,N,2] (or [K,2,N] with actions_soa)."""

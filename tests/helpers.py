@@ -78,6 +78,7 @@ class OracleBackend:
         self.reward64 = torch.zeros(n, dtype=torch.float64)
         self.energy = torch.zeros(n, dtype=torch.float64)
         self.status = torch.zeros(n, dtype=torch.uint8)
+        self.final_obs = torch.zeros((12, n), dtype=torch.float32)
 
     def close(self):
         pass
@@ -130,15 +131,6 @@ class OracleBackend:
         a = np.ascontiguousarray(a.T)          # [N,2]
         f64 = a.dtype == np.float64
         targets = np.asarray(self.cfg.target_states, dtype=np.float64).reshape(-1, 3)
-        if autoreset:
-            for i in np.nonzero(self.done)[0]:
-                s = self.states[i]
-                m, t = device_reset_draw(self.cfg.seed, self.env_id0 + int(i), s.rng_step, targets)
-                s.m[:] = list(m)
-                s.target[:] = list(t)
-                s.total_energy = 0.0
-                s.step_count = 0
-                self.done[i] = 0
         if f64:
             # float64 actions: the safety clamp runs in float64 (monitoring.py:304-313 on a float64 array); the
             # oracle's C entry takes float32, so apply the clamp here and pass values float32 can carry exactly
@@ -155,6 +147,18 @@ class OracleBackend:
             trunc[i] = o.truncated
             status[i] = o.status
             self.done[i] = 1 if (o.terminated or o.truncated) else 0
+            if autoreset and self.done[i]:
+                # same-step auto-reset (csrc/spintorque_hip.hip): terminal obs -> final_obs, redraw, obs of the new episode
+                s = self.states[i]
+                self.final_obs[:, i] = obs[:, i]
+                m, t = device_reset_draw(self.cfg.seed, self.env_id0 + i, s.rng_step, targets)
+                s.m[:] = list(m)
+                s.target[:] = list(t)
+                s.total_energy = 0.0
+                s.step_count = 0
+                s.last_action[:] = [0.0, 0.0]
+                self.done[i] = 0
+                self._obs_of(i, obs)
 
     def step(self, actions, autoreset=False):
         a = torch.as_tensor(actions).cpu().numpy()
