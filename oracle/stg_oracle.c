@@ -48,8 +48,8 @@ void stgo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t o
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-/* Normal stream of one (env, env step): xoshiro128++ seeded by Philox4x32-10(key = seed, counter = (env_id, env_step,
- * tag)); consecutive outputs -> 24-bit uniforms -> fp32 Box-Muller pairs; RHS call j consumes normals 3j..3j+2 (even
+/* Normal stream of one (env, env step): xoshiro128+ seeded by Philox4x32-10(key = seed, counter = (env_id, env_step,
+ * tag)); consecutive outputs -> 23-bit uniforms -> fp32 Box-Muller pairs; RHS call j consumes normals 3j..3j+2 (even
  * calls draw two pairs and keep the 4th normal for the next, odd, call).  Same construction as the HIP kernels
  * (csrc/stg_physics.hpp: NormalStream), restated. */
 typedef struct { uint32_t s[4]; float carry; uint32_t calls; } nstream;
@@ -64,17 +64,21 @@ static void ns_init(nstream* g, uint64_t seed, uint64_t env_id, uint32_t env_ste
 }
 static uint32_t ns_next(nstream* g) {
     uint32_t* s = g->s;
-    uint32_t a = s[0] + s[3];
-    uint32_t result = ((a << 7) | (a >> 25)) + s[0];
+    uint32_t result = s[0] + s[3];                 /* xoshiro128+ */
     uint32_t t = s[1] << 9;
     s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t;
     s[3] = (s[3] << 11) | (s[3] >> 21);
     return result;
 }
+/* 23-bit uniform in (0,1): top 23 bits as the mantissa of a float in [1,2), minus (1 - 2^-24) */
+static float ns_uniform(nstream* g) {
+    union { uint32_t u; float f; } v;
+    v.u = (ns_next(g) >> 9) | 0x3F800000u;
+    return v.f - 0.99999994f;
+}
 static void ns_pair(nstream* g, float* a, float* b) {
-    const float sc = 1.0f / 16777216.0f;
-    float u0 = ((float)(ns_next(g) >> 8) + 0.5f) * sc;
-    float u1 = ((float)(ns_next(g) >> 8) + 0.5f) * sc;
+    float u0 = ns_uniform(g);
+    float u1 = ns_uniform(g);
     float r = sqrtf(-2.0f * logf(u0));
     const float two_pi = 6.28318530717958647692f;
     *a = r * cosf(two_pi * u1);

@@ -131,7 +131,7 @@ void stgo_env_step_batch(int64_t n, stgo_env_state* s, const float* actions /*[n
                          uint64_t env_id0, stgo_step_out* out, int n_threads);
 
 /* thermal-field generator, the same construction as the HIP kernels' (restated, not shared code): per (env, env step)
- * one xoshiro128++ stream seeded by Philox4x32-10(key = seed, counter = (env_id, env_step, tag)), 24-bit uniforms,
+ * one xoshiro128+ stream seeded by Philox4x32-10(key = seed, counter = (env_id, env_step, tag)), 23-bit uniforms,
  * fp32 Box-Muller pairs, RHS call j consuming normals 3j..3j+2.  stgo_thermal_normals returns the normals of call
  * `call_idx` (replaying the stream from call 0). */
 void stgo_thermal_normals(uint64_t seed, uint64_t env_id, uint32_t env_step, uint32_t call_idx, double z[3]);

@@ -124,9 +124,9 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 }
 
 // The thermal field needs three standard normals per RHS call.  Per (env, env step) the kernels run ONE stream:
-//   state   : xoshiro128++ (Blackman & Vigna), seeded by Philox4x32-10(key = seed, counter = (env_id, env_step, tag))
+//   state   : xoshiro128+ (Blackman & Vigna), seeded by Philox4x32-10(key = seed, counter = (env_id, env_step, tag))
 //             -- counter-based seeding keeps every env's stream independent of the batch partition;
-//   normals : consecutive outputs (u_2p, u_2p+1) -> 24-bit uniforms in (0,1) -> one fp32 Box-Muller pair on the
+//   normals : consecutive outputs (u_2p, u_2p+1) -> 23-bit uniforms in (0,1) -> one fp32 Box-Muller pair on the
 //             transcendental unit (v_log_f32 / v_sin_f32 / v_cos_f32 take log2 and revolutions natively);
 //   calls   : RHS call j takes normals 3j..3j+2, so even calls draw two pairs and keep the 4th normal, odd calls draw
 //             one pair and use the kept one first: 1.5 pairs per call, no waste.
@@ -140,18 +140,22 @@ struct NormalStream {
         s0 = r[0]; s1 = r[1]; s2 = r[2]; s3 = r[3] | 1u;     // never the all-zero state
         carry = 0.0f;
     }
+    // xoshiro128+ (Blackman & Vigna; the variant its authors recommend for floating-point generation: the weak low
+    // bits are discarded, only the top 23 bits of each output are used)
     __device__ __forceinline__ uint32_t next() {
-        const uint32_t a = s0 + s3;
-        const uint32_t result = ((a << 7) | (a >> 25)) + s0;
+        const uint32_t result = s0 + s3;
         const uint32_t t = s1 << 9;
         s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= t;
         s3 = (s3 << 11) | (s3 >> 21);
         return result;
     }
+    // uniform in (0,1) with 23-bit resolution: top 23 bits become the mantissa of a float in [1,2), minus (1 - 2^-24)
+    __device__ __forceinline__ float uniform() {
+        return __uint_as_float((next() >> 9) | 0x3F800000u) - 0.99999994f;
+    }
     __device__ __forceinline__ void pair(float& a, float& b) {
-        const float sc = 1.0f / 16777216.0f;
-        const float u0 = ((float)(next() >> 8) + 0.5f) * sc;
-        const float u1 = ((float)(next() >> 8) + 0.5f) * sc;
+        const float u0 = uniform();
+        const float u1 = uniform();
         const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));   // sqrt(-2 ln u0), raw v_sqrt_f32
         a = r * __builtin_amdgcn_cosf(u1);
         b = r * __builtin_amdgcn_sinf(u1);
