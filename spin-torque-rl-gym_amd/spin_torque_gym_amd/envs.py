@@ -194,6 +194,10 @@ class SpinTorqueVecEnv:
     def get_state(self):
         return self.backend.get_state()
 
+    def get_health_report(self):
+        from .harness import health_report
+        return health_report(self)
+
     def close(self):
         self.backend.close()
 
@@ -380,8 +384,12 @@ class SpinTorqueEnv(_EnvBase):
         return {"method": self.solver_name, "solve_count": self._solve_count, "timeout_count": 0,
                 "last_solve_time": 0.0, "timeout_rate": 0.0, "avg_solve_time": 0.0, "backend": "hip/gfx950"}
 
+    def get_health_report(self):
+        from .harness import health_report
+        return health_report(self)
+
     def get_performance_stats(self):
-        return {"profiler": {}, "optimizer": {}, "solver": self.get_solver_info(), "health": {}}
+        return {"profiler": {}, "optimizer": {}, "solver": self.get_solver_info(), "health": self.get_health_report()}
 
     def analyze_episode(self):
         if not self.episode_history:

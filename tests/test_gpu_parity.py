@@ -483,3 +483,18 @@ def test_same_step_autoreset_vs_oracle(stg):
     # after a reset the observation's step/energy/last-action fields are those of a fresh episode
     o = outs[0][2]["obs"][outs[0][2]["trunc"]]
     assert np.all(o[:, 8] == 1.0) and np.all(o[:, 9] == 0.0) and np.all(o[:, 10] == 0.0) and np.all(o[:, 11] == 0.0)
+
+
+def test_harness_parity_single_env_rate_and_health(stg):
+    """The reference's own gates on this path (tests/integration/test_environment.py:457-489: >= 10 steps/s;
+    cli.py benchmark loop) and the health-report shape."""
+    from spin_torque_gym_amd.harness import benchmark_physics_simulation, benchmark_vector_env
+    r = benchmark_physics_simulation(steps=50, include_thermal_fluctuations=False)
+    assert r["steps_per_second"] >= 10, r
+    v = benchmark_vector_env(4096, steps=3, include_thermal_fluctuations=False)
+    h = v["health"]
+    assert set(h) >= {"timestamp", "health_status", "health_issues", "performance_metrics", "recent_performance"}
+    assert h["performance_metrics"]["total_steps"] == 4096 * 5
+    # default STT parameters + random currents: almost every solve fails (SURVEY H3) and the report says so
+    assert h["performance_metrics"]["solver_failure_rate"] > 0.9 and h["health_status"] == "WARNING"
+    print("single-env steps/s", r["steps_per_second"], " vector env-steps/s", v["env_steps_per_second"])
