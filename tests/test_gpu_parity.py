@@ -498,3 +498,68 @@ def test_harness_parity_single_env_rate_and_health(stg):
     # default STT parameters + random currents: almost every solve fails and the report says so
     assert h["performance_metrics"]["solver_failure_rate"] > 0.9 and h["health_status"] == "WARNING"
     print("single-env steps/s", r["steps_per_second"], " vector env-steps/s", v["env_steps_per_second"])
+
+
+def test_step_is_hip_graph_capturable(stg):
+    """stg_step enqueues only kernels on the caller's stream (no allocation, no synchronisation), so a caller can
+    capture plan + step into a hipGraph and replay it; the replay gives the same bits as eager launches."""
+    from spin_torque_gym_amd.backend import EnvConfig, HipBackend
+    n = 8192
+    table = [_flat(stg, stt_default_params(volume=8.75e-11))]
+    cfg = EnvConfig(solver="rk4", include_thermal_fluctuations=True, seed=3, lane_sort=True)
+    rng = np.random.default_rng(0)
+    acts = torch.tensor(_uniform_actions(2e6, 1e-10, 3e-10)(rng, n, 0).T.copy(), device="cuda")
+    res = []
+    for use_graph in (False, True):
+        b = HipBackend(n, cfg); b.set_params(table); b.reset(None, None, None, 5)
+        a_static = acts.clone()
+        if use_graph:
+            st0 = {k: v.clone() for k, v in b.get_state().items()}     # pristine state (counters at 0)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                b.step(a_static)                                  # warm-up on the side stream (loads the code objects)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=s):
+                    b.step(a_static)
+            b.set_state(st0); torch.cuda.synchronize()
+            for _ in range(3):
+                g.replay()
+        else:
+            for _ in range(3):
+                b.step(a_static)
+        torch.cuda.synchronize()
+        res.append((b.obs.clone(), b.get_state()["m"].clone(), b.counters()["env_steps"]))
+        b.close()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+def test_config5_shard_size_and_ragged_batches(stg):
+    """Sizes: one config-5 shard (131 072 envs) and the full 1 048 576 on one GPU; ragged batches (N not a multiple of
+    the wavefront, N = 1).  Size-independent properties: |m| = 1, counters add up, sub-batches equal the full batch."""
+    from spin_torque_gym_amd.backend import EnvConfig, HipBackend
+    table = [_flat(stg, stt_default_params(volume=8.75e-11))]
+    cfg = EnvConfig(solver="rk4", include_thermal_fluctuations=True, seed=17)
+    n = 1048576
+    g = torch.Generator().manual_seed(1)
+    v = torch.randn((3, n), generator=g, dtype=torch.float64)
+    m0 = v / torch.linalg.norm(v, dim=0)
+    tgt = torch.zeros((3, n), dtype=torch.float64); tgt[2] = 1.0
+    act = torch.empty((2, n), dtype=torch.float32)
+    act[0] = (torch.rand(n, generator=g) * 2 - 1) * 2e6
+    act[1] = 1e-10 + torch.rand(n, generator=g) * 2e-10
+
+    def run(lo, hi):
+        b = HipBackend(hi - lo, cfg, env_id0=lo)
+        b.set_params(table)
+        b.reset(None, m0[:, lo:hi], tgt[:, lo:hi], 1)
+        b.step(act[:, lo:hi])
+        out = (b.obs.clone(), b.reward64.clone(), b.get_state()["m"].clone(), b.counters())
+        b.close()
+        return out
+    obs, rew, m, c = run(0, n)
+    assert c["env_steps"] == n and c["work_units"] >= 100 * n
+    assert torch.all(torch.abs(torch.linalg.norm(m, dim=0) - 1) < 1e-14) and torch.isfinite(obs).all()
+    for lo, hi in ((0, 1), (5, 68), (1000, 1000 + 131072), (n - 77, n)):       # N = 1, ragged, a config-5 shard, the tail
+        o2, r2, m2, _ = run(lo, hi)
+        assert torch.equal(o2, obs[:, lo:hi]) and torch.equal(r2, rew[lo:hi]) and torch.equal(m2, m[:, lo:hi])
