@@ -177,6 +177,9 @@ class SpinTorqueVecEnv:
             t = t.unsqueeze(0).expand(self.num_envs, 3)
         if tuple(t.shape) != (self.num_envs, 3):
             raise ValueError(f"expected [N,3] or [3], got {tuple(t.shape)}")
+        # device.validate_magnetization (base_device.py:108-116) raises for a zero vector; the kernel then normalises
+        if not bool(torch.all(torch.linalg.norm(t, dim=1) >= 1e-12)) or not bool(torch.isfinite(t).all()):
+            raise ValueError("Magnetization vector cannot be zero")
         return t.t().contiguous()
 
     # -- checkpoint / resume ---------------------------------------------------------------------------

@@ -140,6 +140,8 @@ def test_vec_env_layout_and_state_dict(stg):
     env2.load_state_dict(sd)
     o2, r2, *_ = env2.step(a)
     assert torch.equal(o1, o2) and torch.equal(r1, r2)
+    with pytest.raises(ValueError, match="zero"):
+        env.reset(options={"initial_state": np.zeros((n, 3))})
     # masked reset only touches the selected envs
     before = env.get_state()["m"].clone()
     mask = torch.tensor([1, 0, 0, 1, 0, 0], dtype=torch.uint8)
