@@ -166,13 +166,34 @@ __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned long 
     if ((int)__lane_id() == __builtin_ctzll(active) && sum) atomicAdd(dst, sum);
 }
 
+constexpr int PLAN_BUCKETS = 256;     // 20 ps of pulse duration per bucket at the default 5 ns maximum
+constexpr int PLAN_THREADS = 1024;
+constexpr int PLAN_ITEMS = 4;
+constexpr int TILE_ENVS = PLAN_THREADS * PLAN_ITEMS;   // 4096 envs sorted together (one plan workgroup)
+constexpr int TILE_WAVES = TILE_ENVS / 64;             // = 64 wavefronts of the step launch
+
+// Which 64-slot block of the schedule a workgroup takes.  With the sorted schedule, a tile's 64 wavefronts should share
+// an XCD (so its L2 merges their scattered accesses) and, across tiles, the longest wavefronts should start first.
+// Workgroups are observed to be dealt round-robin over the 8 XCDs (b % 8 labels the XCD group; a speed heuristic only,
+// never a correctness assumption): XCD group r takes tiles r, r+8, r+16, ... and walks them wave-rank-major
+// (rank 0 = longest wavefront of every tile first).  Tiles beyond the last complete group of 8 keep the identity map.
+__device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nblocks, bool sorted) {
+    if (!sorted) return b;
+    const uint32_t tiles8 = (nblocks / (8 * TILE_WAVES)) * 8;        // tiles in complete groups of 8
+    if (b >= tiles8 * TILE_WAVES) return b;
+    const uint32_t r = b % 8, q = b / 8;                              // XCD group, position inside the group
+    const uint32_t tiles_per_xcd = tiles8 / 8;
+    const uint32_t w = q / tiles_per_xcd, t = (q % tiles_per_xcd) * 8 + r;
+    return (int64_t)t * TILE_WAVES + w;
+}
+
 // ------------------------------------------------------------------------------------------------
 // env.step kernel (A10-A14 around the solver), K fused steps per launch
 // ------------------------------------------------------------------------------------------------
 template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, typename AT>
 __global__ void __launch_bounds__(64) stg_step_kernel(const StepArgs a) {
     __shared__ double s_tab[MULTI ? STG_MAX_CLASSES * C_COUNT : 1];
-    const int64_t lane_slot = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t lane_slot = stg_slot_block(blockIdx.x, gridDim.x, a.perm != nullptr) * 64 + threadIdx.x;
     const bool in_range = lane_slot < a.N;
     // duration-sorted schedule: slot j of the launch integrates env perm[j], so the 64 lanes of a wavefront have
     // (nearly) equal trip counts; all state and outputs stay at the env's own index
@@ -356,14 +377,15 @@ __global__ void stg_normals_kernel(uint64_t seed, int64_t env_id0, int64_t N, ui
 }
 
 // ------------------------------------------------------------------------------------------------
-// lane schedule: counting sort of the envs by this step's integration work (descending)
+// lane schedule: tile-local counting sort of the envs by this step's integration work (descending)
 // ------------------------------------------------------------------------------------------------
 // The trip count of a lane is set by its pulse duration (RK4: n = T/dt sub-steps; RK45: attempts ~ T / 0.65 ps), which
-// the agent chooses per env: U[0.1, 1] ns gives a mean/max ratio of 0.55 inside a wavefront.  Three tiny kernels
-// (histogram in LDS -> scan -> scatter) build a permutation with equal-work envs adjacent; cost ~10 us per step.
-constexpr int PLAN_BUCKETS = 256;     // 20 ps of pulse duration per bucket at the default 5 ns maximum
-constexpr int PLAN_THREADS = 1024;
-constexpr int PLAN_ITEMS = 4;         // envs per thread: 4096 envs per workgroup share one global atomic per bucket
+// the agent chooses per env: U[0.1, 1] ns gives a mean/max ratio of 0.55 inside a wavefront.  One kernel sorts each
+// TILE of 4096 consecutive envs (= 64 wavefronts) by work in LDS (histogram -> scan -> scatter, no global atomics)
+// and writes a tile-local permutation; slot j of the step launch then integrates env perm[j], so the lanes of a
+// wavefront have (nearly) equal trip counts while every access of a wavefront stays inside its tile's 32 KB window of
+// each SoA row.  The step kernel places a tile's 64 wavefronts on ONE XCD (stg_slot_block), whose L2 then merges the
+// tile's scattered 4-8 B accesses into full lines before they reach HBM.
 
 struct PlanArgs {
     const void* actions;      // [2][N] of the first fused step
@@ -372,8 +394,7 @@ struct PlanArgs {
     double max_current, max_duration;
     const uint8_t* done;      // with skip_done: finished envs go last (no work)
     int32_t skip_done;
-    uint8_t* key;
-    uint32_t *hist, *cursor, *perm;
+    uint32_t* perm;
 };
 
 __device__ __forceinline__ int plan_key(const PlanArgs& a, int64_t i) {
@@ -384,50 +405,14 @@ __device__ __forceinline__ int plan_key(const PlanArgs& a, int64_t i) {
     const double w = fmax(T, 1e-10) / a.max_duration;          // below 0.1 ns the RK4 sub-step count stays at ~100
     int b = (int)(w * (PLAN_BUCKETS - 1));
     b = b < 0 ? 0 : (b > PLAN_BUCKETS - 2 ? PLAN_BUCKETS - 2 : b);
-    return (PLAN_BUCKETS - 2) - b;                             // descending work: long pulses are dispatched first
+    return (PLAN_BUCKETS - 2) - b;                             // descending work: long pulses first
 }
 
-__global__ void __launch_bounds__(PLAN_THREADS) stg_plan_hist_kernel(const PlanArgs a) {
-    __shared__ uint32_t h[PLAN_BUCKETS];
-    if (threadIdx.x < PLAN_BUCKETS) h[threadIdx.x] = 0;
-    __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * (PLAN_THREADS * PLAN_ITEMS);
-#pragma unroll
-    for (int r = 0; r < PLAN_ITEMS; ++r) {
-        const int64_t i = base + r * PLAN_THREADS + threadIdx.x;
-        if (i < a.N) {
-            const int k = plan_key(a, i);
-            a.key[i] = (uint8_t)k;
-            atomicAdd(&h[k], 1u);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < PLAN_BUCKETS && h[threadIdx.x]) atomicAdd(&a.hist[threadIdx.x], h[threadIdx.x]);
-}
-
-__global__ void __launch_bounds__(PLAN_BUCKETS) stg_plan_scan_kernel(uint32_t* hist, uint32_t* cursor) {
-    __shared__ uint32_t s[PLAN_BUCKETS];
-    const int t = threadIdx.x;
-    const uint32_t v = hist[t];
-    s[t] = v;
-    __syncthreads();
-    for (int off = 1; off < PLAN_BUCKETS; off <<= 1) {         // Hillis-Steele inclusive scan
-        const uint32_t add = (t >= off) ? s[t - off] : 0u;
-        __syncthreads();
-        s[t] += add;
-        __syncthreads();
-    }
-    cursor[t] = s[t] - v;                                      // exclusive start of bucket t
-    hist[t] = 0;                                               // ready for the next step
-}
-
-// Workgroup-aggregated scatter: ranks inside the workgroup come from LDS atomics, each workgroup reserves its range
-// of a bucket with ONE global atomic (per-address contention N/4096 instead of N/buckets).
-__global__ void __launch_bounds__(PLAN_THREADS) stg_plan_scatter_kernel(const PlanArgs a) {
+__global__ void __launch_bounds__(PLAN_THREADS) stg_plan_tile_kernel(const PlanArgs a) {
     __shared__ uint32_t cnt[PLAN_BUCKETS], start[PLAN_BUCKETS];
     if (threadIdx.x < PLAN_BUCKETS) cnt[threadIdx.x] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * (PLAN_THREADS * PLAN_ITEMS);
+    const int64_t base = (int64_t)blockIdx.x * TILE_ENVS;
     uint32_t rank[PLAN_ITEMS];
     int key[PLAN_ITEMS];
 #pragma unroll
@@ -435,17 +420,24 @@ __global__ void __launch_bounds__(PLAN_THREADS) stg_plan_scatter_kernel(const Pl
         const int64_t i = base + r * PLAN_THREADS + threadIdx.x;
         key[r] = -1;
         if (i < a.N) {
-            key[r] = a.key[i];
-            rank[r] = atomicAdd(&cnt[key[r]], 1u);
+            key[r] = plan_key(a, i);
+            rank[r] = atomicAdd(&cnt[key[r]], 1u);             // rank inside the bucket (LDS atomic)
         }
     }
     __syncthreads();
-    if (threadIdx.x < PLAN_BUCKETS && cnt[threadIdx.x]) start[threadIdx.x] = atomicAdd(&a.cursor[threadIdx.x], cnt[threadIdx.x]);
+    if (threadIdx.x < PLAN_BUCKETS) start[threadIdx.x] = cnt[threadIdx.x];
     __syncthreads();
+    for (int off = 1; off < PLAN_BUCKETS; off <<= 1) {         // Hillis-Steele inclusive scan over the 256 buckets
+        uint32_t add = 0;
+        if (threadIdx.x < PLAN_BUCKETS && (int)threadIdx.x >= off) add = start[threadIdx.x - off];
+        __syncthreads();
+        if (threadIdx.x < PLAN_BUCKETS) start[threadIdx.x] += add;
+        __syncthreads();
+    }
 #pragma unroll
     for (int r = 0; r < PLAN_ITEMS; ++r) {
         const int64_t i = base + r * PLAN_THREADS + threadIdx.x;
-        if (key[r] >= 0) a.perm[start[key[r]] + rank[r]] = (uint32_t)i;
+        if (key[r] >= 0) a.perm[base + (start[key[r]] - cnt[key[r]]) + rank[r]] = (uint32_t)i;   // exclusive start
     }
 }
 
@@ -476,8 +468,7 @@ struct stg_ctx {
     int32_t ncls = 0;
     const uint8_t* cls = nullptr;     // caller-owned device pointer
     unsigned long long* counters = nullptr;
-    uint32_t *perm = nullptr, *hist = nullptr, *cursor = nullptr;
-    uint8_t* key = nullptr;
+    uint32_t* perm = nullptr;
     bool have_params = false, have_state = false;
     bool axis_z = false;              // every class has easy axis = +z exactly: the specialised Simple RHS applies
     bool axis_z_llgs = false;         // every class has raw easy axis (0,0,rz) and demag (0,0,Nz): specialised LLGS RHS
@@ -528,8 +519,7 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
     const size_t N = (size_t)n_envs;
     const size_t r8 = al(N * 8), r4 = al(N * 4), r1 = al(N);
-    const size_t total = 7 * r8 + 3 * r4 + 2 * r1 + al(sizeof(double) * STG_MAX_CLASSES * C_COUNT) + 256 +
-                         2 * al(sizeof(uint32_t) * PLAN_BUCKETS);
+    const size_t total = 7 * r8 + 3 * r4 + r1 + al(sizeof(double) * STG_MAX_CLASSES * C_COUNT) + 256;
     hipError_t e = hipMalloc(&c->slab, total);
     if (e != hipSuccess) { delete c; return fail(STG_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     e = hipMemset(c->slab, 0, total);
@@ -543,9 +533,6 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     c->ctab = (double*)p; p += al(sizeof(double) * STG_MAX_CLASSES * C_COUNT);
     c->counters = (unsigned long long*)p; p += 256;
     c->perm = (uint32_t*)p; p += r4;
-    c->key = (uint8_t*)p; p += r1;
-    c->hist = (uint32_t*)p; p += al(sizeof(uint32_t) * PLAN_BUCKETS);
-    c->cursor = (uint32_t*)p;
     *out = c;
     return STG_OK;
 }
@@ -687,12 +674,9 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
         pa.actions = actions; pa.act_f64 = act_f64; pa.N = ctx->N;
         pa.max_current = ctx->cfg.max_current; pa.max_duration = ctx->cfg.max_duration;
         pa.done = ctx->s.done; pa.skip_done = (ctx->cfg.skip_done && !autoreset) ? 1 : 0;
-        pa.key = ctx->key; pa.hist = ctx->hist; pa.cursor = ctx->cursor; pa.perm = ctx->perm;
-        const int64_t per_wg = (int64_t)PLAN_THREADS * PLAN_ITEMS;
-        const dim3 g((unsigned)((ctx->N + per_wg - 1) / per_wg));
-        hipLaunchKernelGGL(stg_plan_hist_kernel, g, dim3(PLAN_THREADS), 0, st, pa);
-        hipLaunchKernelGGL(stg_plan_scan_kernel, dim3(1), dim3(PLAN_BUCKETS), 0, st, ctx->hist, ctx->cursor);
-        hipLaunchKernelGGL(stg_plan_scatter_kernel, g, dim3(PLAN_THREADS), 0, st, pa);
+        pa.perm = ctx->perm;
+        const dim3 g((unsigned)((ctx->N + TILE_ENVS - 1) / TILE_ENVS));
+        hipLaunchKernelGGL(stg_plan_tile_kernel, g, dim3(PLAN_THREADS), 0, st, pa);
         a.perm = ctx->perm;
     }
     a.actions = actions; a.K = K; a.out_every = out_every ? 1 : 0; a.autoreset = autoreset ? 1 : 0;
