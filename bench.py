@@ -55,7 +55,7 @@ def parse_args():
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--lane-sort", default="auto", choices=["auto", "on", "off"],
-                    help="duration-sorted lane schedule (auto: on for RK45 or > 2 waves per SIMD)")
+                    help="duration-sorted lane schedule (auto = on)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank code path on a single GPU)")
     return ap.parse_args()
@@ -268,7 +268,7 @@ def main():
                    "envs_per_gpu": n_local, "global_envs": n_total, "solver": args.solver, "thermal": bool(args.thermal),
                    "parallelism": f"env-sharded x{world}, one all-gather of 54 B/env per step" if world > 1 else "single GPU"},
         "roofline": roofline(meas, n_local, args.steps, args.solver, thermal=args.thermal,
-                             sorted_schedule=(lane_sort if lane_sort is not None else (args.solver == "rk45" or n_local > 131072))),
+                             sorted_schedule=(lane_sort if lane_sort is not None else True)),
     }
     if rank == 0 and world == 1 and args.also:
         also = []

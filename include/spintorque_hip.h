@@ -87,7 +87,7 @@ typedef struct {
                                        no such guard (its stiff cases simply never return, SURVEY.md headline 3). */
     int32_t skip_done;              /* 1: lanes whose episode already ended are not integrated (wavefront-level
                                        early-out) and report STG_STATUS_INACTIVE; 0: reference behaviour (step anyway) */
-    int32_t lane_sort;              /* schedule of envs onto lanes: 0 = automatic, 1 = always sort the envs by pulse duration
+    int32_t lane_sort;              /* schedule of envs onto lanes: 0 = automatic (sort), 1 = always sort the envs by pulse duration
                                        on the device before each step so that the lanes of a wavefront have equal trip
                                        counts, -1 = identity.  Results are unaffected: an env's arithmetic does not depend
                                        on the lane that runs it. */

@@ -663,11 +663,9 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
     a.counters = ctx->counters;
     hipStream_t st = (hipStream_t)stream;
     a.perm = nullptr;
-    // lane_sort: 0 = automatic (sort when the launch has more than two wavefronts per SIMD for the dispatcher to balance,
-    // or with the adaptive RK45 whose lanes also differ in attempts per step; below that the ~25 us of the three plan
-    // kernels cost more than they save), 1 = always, -1 = never
-    const bool want_sort = ctx->cfg.lane_sort > 0 ||
-                           (ctx->cfg.lane_sort == 0 && (ctx->N > 2 * 64 * 1024 || ctx->cfg.solver == STG_SOLVER_RK45));
+    // lane_sort: 0 = automatic (on: the single LDS-only plan kernel costs ~5 us and the sorted schedule is never slower
+    // once there is more than one wavefront), 1 = always, -1 = never (identity schedule)
+    const bool want_sort = ctx->cfg.lane_sort >= 0;
     if (want_sort && ctx->N > 64) {
         if (ctx->N > 0xFFFFFFFFll) return fail(STG_E_INVALID, "lane sort supports up to 2^32 envs per context");
         PlanArgs pa{};
