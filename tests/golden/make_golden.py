@@ -399,7 +399,26 @@ def G10():
     save("G10_thermal_diffusion", **out)
 
 
-ALL = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10)
+def G11():
+    """simple_euler: SimpleLLGSSolver(method='euler') -- RobustLLGSSolver's fallback integrator -- behind the same gates."""
+    rng = np.random.default_rng(1111)
+    solver = RobustLLGSSolver(method="euler", rtol=1e-3, atol=1e-6, timeout=1e9, max_retries=2, fallback_method="euler",
+                              enable_monitoring=True, enable_validation=True)
+    m0s = unit_rows(rng, 6)
+    rows = []
+    for vol in (50e-9 * 100e-9 * 2e-9, 8.75e-11):
+        params = stt_params(volume=vol)
+        for J in ((0.0,) if vol < 1e-20 else (0.0, 2e6, -5e5)):
+            for T in (1e-10, float(np.float32(2.5e-10)), 5e-10, 5e-12):
+                for i in range(len(m0s)):
+                    r = run_robust(solver, m0s[i], T, params, J)
+                    rows.append((vol, J, T, i, r["success"], *r["m"][-1], r.get("n_steps", -1)))
+    rows = np.array(rows, dtype=float)
+    save("G11_simple_euler", m0=m0s, volume=rows[:, 0], J=rows[:, 1], T=rows[:, 2], m0_index=rows[:, 3].astype(int),
+         success=rows[:, 4].astype(bool), m_final=rows[:, 5:8], n_steps=rows[:, 8].astype(int))
+
+
+ALL = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11)
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

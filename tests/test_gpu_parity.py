@@ -563,3 +563,68 @@ def test_config5_shard_size_and_ragged_batches(stg):
     for lo, hi in ((0, 1), (5, 68), (1000, 1000 + 131072), (n - 77, n)):       # N = 1, ragged, a config-5 shard, the tail
         o2, r2, m2, _ = run(lo, hi)
         assert torch.equal(o2, obs[:, lo:hi]) and torch.equal(r2, rew[lo:hi]) and torch.equal(m2, m[:, lo:hi])
+
+
+def test_euler_solver_vs_golden_g11(stg, golden):
+    g = golden("G11_simple_euler")
+    vols = sorted(set(g["volume"]))
+    table = [_flat(stg, stt_default_params(volume=float(v))) for v in vols]
+    n = len(g["T"])
+    b = _backend(stg, n, table, torch.tensor([vols.index(v) for v in g["volume"]], dtype=torch.uint8), solver="euler",
+                 include_thermal_fluctuations=False)
+    out = b.solve(torch.tensor(np.array([g["m0"][i] for i in g["m0_index"]]).T.copy()), torch.tensor(g["J"].copy()),
+                  torch.tensor(g["T"].copy()))
+    assert np.array_equal(out["success"].cpu().numpy().astype(bool), g["success"])
+    assert np.array_equal(out["n_points"].cpu().numpy(), g["n_steps"])
+    assert np.abs(out["m_final"].cpu().numpy().T - g["m_final"]).max() <= TOL_RK4
+    b.close()
+
+
+@pytest.mark.parametrize("solver", ["rk4", "euler", "rk45"])
+def test_kernel_variant_matrix_vs_oracle(stg, solver):
+    """Every template instantiation of the step kernel (solver x thermal x {one class, class table in LDS} x
+    {easy axis = z specialisation, general axis} x {float32, float64 actions}) against the oracle, one step each."""
+    from helpers import OracleBackend
+    n = 192                                   # three wavefronts
+    vol = 9.7e-6 if solver == "rk45" else 8.75e-11
+    tilt = dict(easy_axis=np.array([0.15, -0.1, 1.0]), demag_factors=np.array([0.1, 0.2, 0.7]))
+    rng = np.random.default_rng(77)
+    from helpers import unit_rows
+    m0 = unit_rows(rng, n)
+    tgt = np.where(rng.integers(0, 2, (n, 1)) == 0, 1.0, -1.0) * np.array([[0.0, 0.0, 1.0]])
+    act = _uniform_actions(2e6, 1e-10, 3e-10)(rng, n, 0)
+    worst = 0.0
+    for thermal in (False, True):
+        for multi in (False, True):
+            for general_axis in (False, True):
+                extra = tilt if general_axis else {}
+                if multi:
+                    kw = dict(device_type=["stt_mram", "vcma_mram"],
+                              device_params=[stt_default_params(volume=vol, **extra),
+                                             vcma_default_params(polarization=0.6, volume=vol * 0.8, **extra)],
+                              class_index=(np.arange(n) % 2).astype(np.uint8))
+                else:
+                    kw = dict(device_params=stt_default_params(volume=vol, **extra))
+                kw.update(include_thermal_fluctuations=thermal, solver=solver, seed=5)
+                res = []
+                for backend in (None, OracleBackend):
+                    env = stg.SpinTorqueVecEnv(n, backend=backend, **kw)
+                    env.reset(options={"initial_state": m0, "target_state": tgt})
+                    o, r, te, tr, info = env.step(torch.from_numpy(act))
+                    res.append((o.cpu().numpy().copy(), info["reward_f64"].cpu().numpy().copy(), te.cpu().numpy().copy(),
+                                info["status"].cpu().numpy().copy(), env.get_state()["m"].cpu().numpy().copy()))
+                    if backend is None:       # float64 actions carrying the same values take the other instantiation
+                        env2 = stg.SpinTorqueVecEnv(n, **kw)
+                        env2.reset(options={"initial_state": m0, "target_state": tgt})
+                        o64, *_ = env2.step(torch.from_numpy(act.astype(np.float64)))
+                        assert torch.equal(o64, o), (solver, thermal, multi, general_axis)
+                        env2.close()
+                    env.close()
+                (o1, r1, t1, s1, m1), (o2, r2, t2, s2, m2) = res
+                tag = (solver, thermal, multi, general_axis)
+                tol = TOL_RK45 if solver == "rk45" else TOL_RK4
+                assert np.array_equal(s1, s2) and np.array_equal(t1, t2), tag
+                assert np.abs(m1 - m2).max() <= tol, (tag, np.abs(m1 - m2).max())
+                assert np.allclose(o1, o2, rtol=3e-7, atol=1e-9) and np.allclose(r1, r2, rtol=1e-9, atol=1e-9), tag
+                worst = max(worst, np.abs(m1 - m2).max())
+    print(solver, "variant matrix worst |dm| =", worst)

@@ -252,3 +252,16 @@ def test_g10_thermal_on_vs_reference(golden, oracle_mod):
             out.append(r["m_final"])
         return np.array(out), np.array(npts)
     check_thermal_diffusion(g, solve_many, 3000, 1500, "oracle")
+
+
+def test_g11_simple_euler(golden, oracle_mod):
+    o = oracle_mod
+    g = golden("G11_simple_euler")
+    c = o.make_config("euler")
+    worst = 0.0
+    for k in range(len(g["T"])):
+        p = o.make_params(stt_default_params(volume=float(g["volume"][k])))
+        r = o.simple_solve(g["m0"][g["m0_index"][k]], g["T"][k], p, c, g["J"][k])
+        assert r["success"] == bool(g["success"][k]) and r["n_steps"] == g["n_steps"][k]
+        worst = max(worst, np.abs(r["m_final"] - g["m_final"][k]).max())
+    assert worst <= 1e-12, worst
