@@ -81,12 +81,13 @@ def volume_for(solver):
     return 9.7e-6 if solver == "rk45" else 8.75e-11
 
 
-def run_config(n_local, solver, thermal, steps, warmup, rank, world, device_index, mixed=False, seed=1234, lane_sort=None):
+def run_config(n_local, solver, thermal, steps, warmup, rank, world, device_index, mixed=False, seed=1234, lane_sort=None,
+               torque_model="reference"):
     """Builds the env, runs warmup + timed steps, returns a dict of measurements (times are this rank's)."""
     import spin_torque_gym_amd as stg
     import torch.distributed as dist
     kw = dict(include_thermal_fluctuations=bool(thermal), temperature=300.0, solver=solver, seed=seed, autoreset=True,
-              lane_sort=lane_sort)
+              lane_sort=lane_sort, torque_model=torque_model)
     if mixed:
         fac = stg.DeviceFactory()
         sot = fac.get_default_parameters("sot_mram"); sot.update(polarization=0.7, volume=volume_for(solver))
@@ -272,14 +273,17 @@ def main():
     }
     if rank == 0 and world == 1 and args.also:
         also = []
-        for name, n, solver, thermal, mixed in (
-                ("cfg2: 4096 STT envs, T=0K, rk45", 4096, "rk45", 0, False),
-                ("cfg2: 4096 STT envs, T=0K, rk4 (the env's own solver)", 4096, "rk4", 0, False),
-                ("cfg3: 65536 STT envs, thermal on, rk4", 65536, "rk4", 1, False),
-                ("cfg4: 262144 mixed STT/SOT/VCMA envs (class table in LDS), T=0K, rk4", 262144, "rk4", 0, True)):
+        for name, n, solver, thermal, mixed, tm in (
+                ("cfg2: 4096 STT envs, T=0K, rk45", 4096, "rk45", 0, False, "reference"),
+                ("cfg2: 4096 STT envs, T=0K, rk4 (the env's own solver)", 4096, "rk4", 0, False, "reference"),
+                ("cfg3: 65536 STT envs, thermal on, rk4", 65536, "rk4", 1, False, "reference"),
+                ("cfg4: 262144 mixed STT/SOT/VCMA envs (class table in LDS), T=0K, rk4, reference RHS for all types",
+                 262144, "rk4", 0, True, "reference"),
+                ("cfg4: 262144 mixed STT/SOT/VCMA envs, T=0K, rk4, device-physics torque terms per type (opt-in)",
+                 262144, "rk4", 0, True, "device")):
             if solver == args.solver and n == n_local and bool(thermal) == bool(args.thermal) and not mixed:
                 continue
-            m = run_config(n, solver, thermal, max(3, args.steps // 2), 1, 0, 1, local_rank, mixed=mixed)
+            m = run_config(n, solver, thermal, max(3, args.steps // 2), 1, 0, 1, local_rank, mixed=mixed, torque_model=tm)
             st = max(3, args.steps // 2)
             also.append({"workload": name, "value": round(n * st / m["wall_s"], 1), "unit": "env-steps/s",
                          "ms_per_step": round(m["wall_s"] / st * 1e3, 4), "roofline": roofline(m, n, st, solver, mixed)})

@@ -87,6 +87,14 @@ typedef struct {
                                        no such guard (its stiff cases simply never return, SURVEY.md headline 3). */
     int32_t skip_done;              /* 1: lanes whose episode already ended are not integrated (wavefront-level
                                        early-out) and report STG_STATUS_INACTIVE; 0: reference behaviour (step anyway) */
+    int32_t torque_model;           /* 0 (default): the reference env's type-agnostic RHS for every device type.
+                                       1: opt-in device-physics torque model for the fixed-step solvers (SURVEY 8f #1,
+                                       BASELINE config 4): SOT classes use SOTMRAMDevice.compute_spin_torque
+                                       (sot_mram.py:163-194) instead of the Slonczewski term, VCMA classes use
+                                       H_k from VCMAMRAMDevice._compute_effective_anisotropy (vcma_mram.py:122-147)
+                                       at V = J R(m) A while the pulse is on.  The reference env never calls these
+                                       formulas; the model is pinned against the device classes, not against env runs. */
+    int32_t reserved;
     int32_t lane_sort;              /* schedule of envs onto lanes: 0 = automatic (sort), 1 = always sort the envs by pulse duration
                                        on the device before each step so that the lanes of a wavefront have equal trip
                                        counts, -1 = identity.  Results are unaffected: an env's arithmetic does not depend
@@ -108,6 +116,11 @@ typedef struct {
     double r_p, r_ap;               /* 'resistance_parallel', 'resistance_antiparallel' */
     double ref_m[3];                /* 'reference_magnetization', raw */
     double r_series;                /* SOT: 0.1*(rho_hm/t_hm)/(area*1e-12) (sot_mram.py:218-223); else 0 */
+    double sot_tau_dl, sot_tau_fl;  /* SOT: tau_dl_factor, tau_fl_factor (sot_mram.py:61-72); else 0 */
+    double sot_sigma[3];            /* SOT: z x current_direction (sot_mram.py:180-186), default (0,1,0) */
+    double vcma_xi;                 /* VCMA: 'vcma_coefficient' */
+    double vcma_td;                 /* VCMA: 'dielectric_thickness' */
+    double vcma_vbd;                /* VCMA: 'breakdown_voltage' */
     int32_t dev_type;               /* STG_DEV_* : selects the compute_resistance form */
     int32_t params_valid;           /* outcome of validate_parameters(params,'stt_mram') (utils/validation.py:176-234),
                                        evaluated by the host mirror; 0 -> every solve falls back (no-op) */
@@ -186,6 +199,15 @@ int stg_solve(stg_ctx* ctx, const double* m0, const double* J, const double* T, 
 int stg_solve_traj(stg_ctx* ctx, const double* m0, const double* J, const double* T, uint32_t env_step,
                    int32_t traj_cap, double* t, double* m, double* energy,
                    double* m_final, int32_t* n_points, uint8_t* success, void* stream);
+
+/* ---- device-class formulas (opt-in torque model) ------------------------------------------- */
+
+/* Evaluates, per env, the device-class formulas the torque model uses: for SOT classes tau_dl, tau_fl of
+ * SOTMRAMDevice.compute_spin_torque(J, m) (double[3][N] each, zeros for other classes), and for VCMA classes
+ * K_eff(volt) of VCMAMRAMDevice._compute_effective_anisotropy (double[N]; the class' K for other classes).
+ * m double[3][N], J, volt double[N]; any output may be NULL. */
+int stg_device_terms(stg_ctx* ctx, const double* m, const double* J, const double* volt, double* tau_dl, double* tau_fl,
+                     double* k_eff, void* stream);
 
 /* ---- thermal field (physics/thermal_model.py:12-137; simple_solver.py:378-386; llgs_solver.py:85-90,111-113) ---- */
 

@@ -15,7 +15,7 @@ _SO = os.path.join(_HERE, "_build", "libstg_oracle.so")
 
 __all__ = ["Params", "Config", "EnvState", "StepOut", "lib", "build", "make_params", "make_config",
            "simple_solve", "llgs_solve", "resistance", "thermal_strength", "env_step", "env_step_batch",
-           "thermal_normals", "parse_action", "simple_dmdt", "llgs_rhs", "DEV_TYPES"]
+           "thermal_normals", "parse_action", "simple_dmdt", "llgs_rhs", "DEV_TYPES", "sot_torque", "vcma_keff"]
 
 DEV_TYPES = {"stt_mram": 0, "sot_mram": 1, "vcma_mram": 2}
 
@@ -24,8 +24,9 @@ class Params(C.Structure):
     _fields_ = [("damping", C.c_double), ("ms", C.c_double), ("ku", C.c_double), ("volume", C.c_double),
                 ("polarization", C.c_double), ("easy_axis", C.c_double * 3), ("demag", C.c_double * 3),
                 ("a_ex", C.c_double), ("area", C.c_double), ("r_p", C.c_double), ("r_ap", C.c_double),
-                ("ref_m", C.c_double * 3), ("r_series", C.c_double), ("dev_type", C.c_int32),
-                ("params_valid", C.c_int32)]
+                ("ref_m", C.c_double * 3), ("r_series", C.c_double), ("sot_tau_dl", C.c_double), ("sot_tau_fl", C.c_double),
+                ("sot_sigma", C.c_double * 3), ("vcma_xi", C.c_double), ("vcma_td", C.c_double), ("vcma_vbd", C.c_double),
+                ("dev_type", C.c_int32), ("params_valid", C.c_int32)]
 
 
 class Config(C.Structure):
@@ -33,7 +34,7 @@ class Config(C.Structure):
                 ("gamma", C.c_double), ("max_step", C.c_double), ("rtol", C.c_double), ("atol", C.c_double),
                 ("max_steps", C.c_int32), ("max_current", C.c_double), ("max_duration", C.c_double),
                 ("success_threshold", C.c_double), ("energy_penalty_weight", C.c_double),
-                ("seed", C.c_uint64), ("max_attempts", C.c_int64)]
+                ("seed", C.c_uint64), ("max_attempts", C.c_int64), ("torque_model", C.c_int32)]
 
 
 class EnvState(C.Structure):
@@ -93,6 +94,10 @@ def lib():
         L.stgo_simple_dmdt.argtypes = [dp, C.POINTER(Params), C.c_double, C.c_double, dp, dp]
         L.stgo_llgs_rhs.restype = None
         L.stgo_llgs_rhs.argtypes = [dp, C.POINTER(Params), C.c_double, C.c_double, dp, dp]
+        L.stgo_sot_torque.restype = None
+        L.stgo_sot_torque.argtypes = [dp, C.c_double, C.POINTER(Params), dp, dp]
+        L.stgo_vcma_keff.restype = C.c_double
+        L.stgo_vcma_keff.argtypes = [C.c_double, C.POINTER(Params)]
         L.stgo_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -143,6 +148,24 @@ def make_params(device_params, device_type="stt_mram"):
     p.ref_m[:] = list(np.asarray(d.get("reference_magnetization", [0, 0, 1]), dtype=float))
     p.dev_type = DEV_TYPES[device_type]
     p.r_series = 0.0
+    p.sot_tau_dl = p.sot_tau_fl = 0.0
+    p.sot_sigma[:] = [0.0, 1.0, 0.0]
+    p.vcma_xi, p.vcma_td, p.vcma_vbd = 0.0, 1e-9, 2.0
+    if device_type == "vcma_mram":
+        # devices/vcma_mram.py:37-40
+        p.vcma_xi = d.get("vcma_coefficient", 100e-6)
+        p.vcma_td = d.get("dielectric_thickness", 1e-9)
+        p.vcma_vbd = d.get("breakdown_voltage", 2.0)
+    if device_type == "sot_mram":
+        # devices/sot_mram.py:35-40,61-72,180-186
+        sha = d.get("spin_hall_angle", 0.1)
+        t_hm_ = d.get("heavy_metal_thickness", 5e-9)
+        eff = sha * d.get("interface_transparency", 0.5) * (t_hm_ / (t_hm_ + d.get("thickness", 1e-9)))
+        p.sot_tau_dl = d.get("damping_like_efficiency", 0.2) * eff
+        p.sot_tau_fl = d.get("field_like_efficiency", 0.1) * eff
+        j_hat = np.asarray(d.get("current_direction", [1.0, 0.0, 0.0]), dtype=float)
+        j_hat = j_hat / np.linalg.norm(j_hat)
+        p.sot_sigma[:] = list(np.cross(np.array([0.0, 0.0, 1.0]), j_hat))
     if device_type == "sot_mram":
         # devices/sot_mram.py:37-38,76-77,218-223
         t_hm = d.get("heavy_metal_thickness", 5e-9)
@@ -156,7 +179,7 @@ def make_params(device_params, device_type="stt_mram"):
 
 def make_config(solver="rk4", thermal=False, temperature=300.0, gamma=2.21e5, max_step=1e-12, rtol=1e-6,
                 atol=1e-9, max_steps=100, max_current=2e6, max_duration=5e-9, success_threshold=0.9,
-                energy_penalty_weight=0.1, seed=0, max_attempts=10_000_000):
+                energy_penalty_weight=0.1, seed=0, max_attempts=10_000_000, torque_model=0):
     c = Config()
     c.solver = {"rk4": 0, "euler": 1, "rk45": 2}[solver]
     c.thermal = int(bool(thermal))
@@ -164,6 +187,7 @@ def make_config(solver="rk4", thermal=False, temperature=300.0, gamma=2.21e5, ma
     c.max_steps, c.max_current, c.max_duration = max_steps, max_current, max_duration
     c.success_threshold, c.energy_penalty_weight = success_threshold, energy_penalty_weight
     c.seed, c.max_attempts = seed, max_attempts
+    c.torque_model = int(torque_model)
     return c
 
 
@@ -244,6 +268,17 @@ def llgs_rhs(y, p, gamma, J, h_thermal=None):
     h = None if h_thermal is None else np.ascontiguousarray(h_thermal, dtype=np.float64)
     lib().stgo_llgs_rhs(_dp(y), C.byref(p), gamma, J, _dp(h) if h is not None else None, _dp(out))
     return out
+
+
+def sot_torque(m, J, p):
+    m = np.ascontiguousarray(m, dtype=np.float64)
+    dl, fl = np.zeros(3), np.zeros(3)
+    lib().stgo_sot_torque(_dp(m), float(J), C.byref(p), _dp(dl), _dp(fl))
+    return dl, fl
+
+
+def vcma_keff(volt, p):
+    return lib().stgo_vcma_keff(float(volt), C.byref(p))
 
 
 def env_step(state, action, p, c, env_id=0):

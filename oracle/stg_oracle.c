@@ -160,6 +160,43 @@ void stgo_simple_dmdt(const double m[3], const stgo_params* p, double gamma, dou
     }
 }
 
+/* SOTMRAMDevice.compute_spin_torque (devices/sot_mram.py:163-194): tau_DL = f_dl J (sigma x m), tau_FL = f_fl J sigma */
+void stgo_sot_torque(const double m[3], double J, const stgo_params* p, double tau_dl[3], double tau_fl[3]) {
+    double sxm[3];
+    cross3(p->sot_sigma, m, sxm);
+    for (int i = 0; i < 3; ++i) {
+        tau_dl[i] = p->sot_tau_dl * J * sxm[i];
+        tau_fl[i] = p->sot_tau_fl * J * p->sot_sigma[i];
+    }
+}
+
+/* VCMAMRAMDevice._compute_effective_anisotropy (devices/vcma_mram.py:122-147) */
+double stgo_vcma_keff(double volt, const stgo_params* p) {
+    double v = fmin(fmax(volt, -p->vcma_vbd), p->vcma_vbd);
+    double change = -p->vcma_xi * fabs(v) / (p->vcma_td * p->vcma_td);
+    double keff = p->ku + change;
+    return fmax(keff, -0.5 * p->ku);
+}
+
+/* Right-hand side of the opt-in device-physics torque model (include/spintorque_hip.h: stg_config.torque_model = 1):
+ * the reference RHS (stgo_simple_dmdt) with, per device type, SOT: no Slonczewski term, + (tau_DL + tau_FL)/(ms V);
+ * VCMA: K_u replaced by K_eff(volt) while the pulse is on.  `on` = the pulse gate of this stage. */
+static void device_dmdt(const double m[3], const stgo_params* p, double gamma, double J, double volt, int on,
+                        const double h_thermal[3], double out[3]) {
+    stgo_params q = *p;
+    double Js = on ? J : 0.0;
+    if (p->dev_type == 2 && on) q.ku = stgo_vcma_keff(volt, p);
+    if (p->dev_type == 1) {
+        stgo_simple_dmdt(m, &q, gamma, 0.0, h_thermal, out);
+        double dl[3], fl[3];
+        stgo_sot_torque(m, Js, p, dl, fl);
+        double msv = p->ms * p->volume;
+        for (int i = 0; i < 3; ++i) out[i] += (dl[i] + fl[i]) / msv;
+    } else {
+        stgo_simple_dmdt(m, &q, gamma, Js, h_thermal, out);
+    }
+}
+
 /* SimpleLLGSSolver._validate_magnetization (simple_solver.py:208-229).  Returns 0 normal, 1 reset to
  * [0,0,1] (non-finite input, tiny norm or non-finite quotient). */
 static int simple_validate(double m[3]) {
@@ -208,6 +245,9 @@ int stgo_simple_solve(const double m0[3], double T, const stgo_params* p, const 
     const int thermal = c->thermal && c->temperature > 0;
     const double hs = thermal ? stgo_thermal_strength(p, c->gamma, c->temperature, 0) : 0.0;
     int zero_row = -1;
+    /* device-physics model: the voltage the env itself computes for the pulse, V = J R(m_before) A
+     * (spin_torque_env.py:475-477), sets K_eff for VCMA classes */
+    const double volt = c->torque_model ? J * stgo_resistance(m0, p) * p->area : 0.0;
     nstream g;
     if (thermal) ns_init(&g, c->seed, env_id, env_step, 0u);
     if (traj && traj_cap_rows > 0) { traj[0] = m[0]; traj[1] = m[1]; traj[2] = m[2]; }
@@ -228,7 +268,8 @@ int stgo_simple_solve(const double m0[3], double T, const stgo_params* p, const 
                 hth[0] = hs * z[0]; hth[1] = hs * z[1]; hth[2] = hs * z[2];
             }
             double f[3];
-            stgo_simple_dmdt(y, p, c->gamma, Jt, thermal ? hth : 0, f);
+            if (c->torque_model) device_dmdt(y, p, c->gamma, J, volt, ts <= T, thermal ? hth : 0, f);
+            else stgo_simple_dmdt(y, p, c->gamma, Jt, thermal ? hth : 0, f);
             for (int j = 0; j < 3; ++j) k[s][j] = dt * f[j];
         }
         double mn[3];

@@ -39,6 +39,9 @@ typedef struct {
     double r_p, r_ap;               /* 'resistance_parallel' / 'resistance_antiparallel' */
     double ref_m[3];                /* 'reference_magnetization' (raw) */
     double r_series;                /* SOT only: 0.1 * (rho_hm/t_hm) / (area*1e-12)  (devices/sot_mram.py:218-223) */
+    double sot_tau_dl, sot_tau_fl;  /* SOT: tau_dl_factor, tau_fl_factor (devices/sot_mram.py:61-72) */
+    double sot_sigma[3];            /* SOT: z x current_direction (devices/sot_mram.py:180-186) */
+    double vcma_xi, vcma_td, vcma_vbd; /* VCMA: vcma_coefficient, dielectric_thickness, breakdown_voltage */
     int32_t dev_type;               /* 0 stt_mram, 1 sot_mram, 2 vcma_mram */
     int32_t params_valid;           /* result of utils/validation.py:176-234 as 'stt_mram' (host-evaluated) */
 } stgo_params;
@@ -59,6 +62,7 @@ typedef struct {
     double energy_penalty_weight;   /* 0.1 */
     uint64_t seed;                  /* thermal-field Philox key */
     int64_t max_attempts;           /* RK45 attempt budget per solve (guard; reference has none) */
+    int32_t torque_model;           /* 0 reference RHS; 1 device-physics torque model (include/spintorque_hip.h) */
 } stgo_config;
 
 /* per-env mutable state (envs/spin_torque_env.py:133-139) */
@@ -104,6 +108,11 @@ int64_t stgo_llgs_solve(const double m0[3], double T, const stgo_params* p, cons
                         double J, uint64_t env_id, uint32_t env_step,
                         double m_final[3], int32_t* success, int64_t* n_attempts,
                         double* t_out, double* m_out, double* e_out, double* tq_out, int64_t cap);
+
+/* ---- opt-in device-physics terms: SOTMRAMDevice.compute_spin_torque (devices/sot_mram.py:163-194)
+ *      and VCMAMRAMDevice._compute_effective_anisotropy (devices/vcma_mram.py:122-147) ---- */
+void stgo_sot_torque(const double m[3], double J, const stgo_params* p, double tau_dl[3], double tau_fl[3]);
+double stgo_vcma_keff(double volt, const stgo_params* p);
 
 /* ---- A9: compute_resistance (devices/stt_mram.py:78-94, sot_mram.py:196-228, vcma_mram.py:236-257) ---- */
 double stgo_resistance(const double m[3], const stgo_params* p);

@@ -100,7 +100,7 @@ __device__ __forceinline__ LlgsEnergyK load_energy(const double* r) {
     return LlgsEnergyK{r[C_KUV], r[C_EDEMAG], V3{r[C_RX], r[C_RY], r[C_RZ]}, V3{r[C_NX], r[C_NY], r[C_NZ]}};
 }
 
-template <int SOLVER, bool THERMAL, bool RECORD, bool AXIS_Z>
+template <int SOLVER, bool THERMAL, bool RECORD, bool AXIS_Z, bool DEVPHYS>
 __device__ __forceinline__ SolveOut run_solver(const V3& m, double J, double T, const double* row, const CfgView& c,
                                                const RngKey& rk, const Recorder& rec) {
     if (SOLVER == STG_SOLVER_RK45) {
@@ -108,12 +108,32 @@ __device__ __forceinline__ SolveOut run_solver(const V3& m, double J, double T, 
         LlgsEnergyK ek{};
         if (RECORD) ek = load_energy(row);
         return llgs_solve<THERMAL, RECORD, AXIS_Z>(m, J, T, k, row[C_BETA], row[C_BETAP], c.rtol, c.atol, c.max_step,
-                                           c.max_attempts, rk, rec, ek);
+                                                   c.max_attempts, rk, rec, ek);
     }
     const SimpleK k = load_simple(row);
-    return simple_solve<SOLVER == STG_SOLVER_EULER ? 1 : 0, THERMAL, RECORD, AXIS_Z>(m, J, T, k, row[C_POL], row[C_MSV],
-                                                                           row[C_VALID] != 0.0, c.temperature,
-                                                                           c.max_step, rk, rec);
+    DevTorque dv{0.0, 0.0, V3{0.0, 1.0, 0.0}, k.hk, false};
+    double pol = row[C_POL];
+    if (DEVPHYS) {
+        // per-lane coefficients of the device-physics torque model (stg_physics.hpp: DevTorque)
+        const int kind = (int)row[C_DEVTYPE];
+        const bool sot = kind == STG_DEV_SOT;
+        dv.any_sot = __ballot(sot) != 0ull;
+        dv.sigma = V3{row[C_SIGX], row[C_SIGY], row[C_SIGZ]};
+        if (sot) {
+            pol = 0.0;                                           // no Slonczewski term for SOT lanes
+            dv.sdl = row[C_SOT_DL] * J / row[C_MSV];
+            dv.sfl = row[C_SOT_FL] * J / row[C_MSV];
+        }
+        if (kind == STG_DEV_VCMA) {
+            // V = J R(m_before) A, the voltage the env computes for this pulse (spin_torque_env.py:475-477)
+            const V3 ref{row[C_REFX], row[C_REFY], row[C_REFZ]};
+            const double r = resistance(m, kind, row[C_RP], row[C_RAP], row[C_TMR], ref, row[C_RSERIES]);
+            const double keff = vcma_keff(J * r * row[C_AREA], row[C_KU], row[C_VCMA_XI], row[C_VCMA_TD2], row[C_VCMA_VBD]);
+            dv.hk_pulse = (2 * keff) / row[C_MU0MS];
+        }
+    }
+    return simple_solve<SOLVER == STG_SOLVER_EULER ? 1 : 0, THERMAL, RECORD, AXIS_Z, DEVPHYS>(
+        m, J, T, k, pol, row[C_MSV], row[C_VALID] != 0.0, c.temperature, c.max_step, rk, rec, dv);
 }
 
 // SpinTorqueEnv.reset draws (spin_torque_env.py:286-299) from the device generator: normal(0,1,3) normalised and a
@@ -166,7 +186,8 @@ __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned long 
     if ((int)__lane_id() == __builtin_ctzll(active) && sum) atomicAdd(dst, sum);
 }
 
-constexpr int PLAN_BUCKETS = 256;     // 20 ps of pulse duration per bucket at the default 5 ns maximum
+constexpr int PLAN_DUR = 256;         // 20 ps of pulse duration per bucket at the default 5 ns maximum
+constexpr int PLAN_BUCKETS = 3 * PLAN_DUR;   // x device kind (device-physics torque model: type-uniform wavefronts)
 constexpr int PLAN_THREADS = 1024;
 constexpr int PLAN_ITEMS = 4;
 constexpr int TILE_ENVS = PLAN_THREADS * PLAN_ITEMS;   // 4096 envs sorted together (one plan workgroup)
@@ -190,7 +211,7 @@ __device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nblocks, 
 // ------------------------------------------------------------------------------------------------
 // env.step kernel (A10-A14 around the solver), K fused steps per launch
 // ------------------------------------------------------------------------------------------------
-template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, typename AT>
+template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, bool DEVPHYS, typename AT>
 __global__ void __launch_bounds__(64) stg_step_kernel(const StepArgs a) {
     __shared__ double s_tab[MULTI ? STG_MAX_CLASSES * C_COUNT : 1];
     const int64_t lane_slot = stg_slot_block(blockIdx.x, gridDim.x, a.perm != nullptr) * 64 + threadIdx.x;
@@ -231,7 +252,7 @@ __global__ void __launch_bounds__(64) stg_step_kernel(const StepArgs a) {
         } else {
             const double prev_align = dot(m, tgt);                                   // spin_torque_env.py:338-339
             const RngKey rk{a.c.seed, env_id, rng};
-            const SolveOut so = run_solver<SOLVER, THERMAL, false, AXIS_Z>(m, J, T, row, a.c, rk, norec);
+            const SolveOut so = run_solver<SOLVER, THERMAL, false, AXIS_Z, DEVPHYS>(m, J, T, row, a.c, rk, norec);
             if (fabs(J) > 1e-12) {                                                   // spin_torque_env.py:474-480
                 const V3 ref{row[C_REFX], row[C_REFY], row[C_REFZ]};
                 const double r = resistance(m, (int)row[C_DEVTYPE], row[C_RP], row[C_RAP], row[C_TMR], ref, row[C_RSERIES]);
@@ -305,7 +326,7 @@ __global__ void __launch_bounds__(64) stg_solve_kernel(const SolveArgs a) {
     const V3 m0{a.m0[i], a.m0[N + i], a.m0[2 * N + i]};
     const RngKey rk{a.c.seed, (uint64_t)(a.env_id0 + i), a.env_step};
     const Recorder rec{a.traj_t, a.traj_m, a.traj_e, N, i, a.traj_cap};
-    const SolveOut so = run_solver<SOLVER, THERMAL, RECORD, false>(m0, a.J[i], a.T[i], row, a.c, rk, rec);
+    const SolveOut so = run_solver<SOLVER, THERMAL, RECORD, false, false>(m0, a.J[i], a.T[i], row, a.c, rk, rec);
     a.m_final[i] = so.m.x; a.m_final[N + i] = so.m.y; a.m_final[2 * N + i] = so.m.z;
     if (a.n_points) a.n_points[i] = so.n;
     if (a.success) a.success[i] = so.ok ? 1 : 0;
@@ -394,6 +415,9 @@ struct PlanArgs {
     double max_current, max_duration;
     const uint8_t* done;      // with skip_done: finished envs go last (no work)
     int32_t skip_done;
+    const uint8_t* cls;       // device-physics torque model with several classes: group lanes by device kind
+    const double* ctab;
+    int32_t by_kind;
     uint32_t* perm;
 };
 
@@ -401,23 +425,26 @@ __device__ __forceinline__ int plan_key(const PlanArgs& a, int64_t i) {
     double J, T;
     if (a.act_f64) parse_action<double>(((const double*)a.actions)[i], ((const double*)a.actions)[a.N + i], a.max_current, a.max_duration, J, T);
     else parse_action<float>(((const float*)a.actions)[i], ((const float*)a.actions)[a.N + i], a.max_current, a.max_duration, J, T);
-    if (a.skip_done && a.done[i]) return PLAN_BUCKETS - 1;
+    if (a.skip_done && a.done[i]) return (a.by_kind ? PLAN_BUCKETS : PLAN_DUR) - 1;
     const double w = fmax(T, 1e-10) / a.max_duration;          // below 0.1 ns the RK4 sub-step count stays at ~100
-    int b = (int)(w * (PLAN_BUCKETS - 1));
-    b = b < 0 ? 0 : (b > PLAN_BUCKETS - 2 ? PLAN_BUCKETS - 2 : b);
-    return (PLAN_BUCKETS - 2) - b;                             // descending work: long pulses first
+    int b = (int)(w * (PLAN_DUR - 1));
+    b = b < 0 ? 0 : (b > PLAN_DUR - 2 ? PLAN_DUR - 2 : b);
+    const int kind = a.by_kind ? (int)a.ctab[(int)a.cls[i] * C_COUNT + C_DEVTYPE] : 0;
+    return kind * PLAN_DUR + (PLAN_DUR - 2) - b;               // descending work inside each kind: long pulses first
 }
 
 __global__ void __launch_bounds__(PLAN_THREADS) stg_plan_tile_kernel(const PlanArgs a) {
     __shared__ uint32_t cnt[PLAN_BUCKETS], start[PLAN_BUCKETS];
-    if (threadIdx.x < PLAN_BUCKETS) cnt[threadIdx.x] = 0;
+    const int nb = a.by_kind ? PLAN_BUCKETS : PLAN_DUR;       // buckets in use
+    const int tid = threadIdx.x;
+    if (tid < nb) cnt[tid] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * TILE_ENVS;
     uint32_t rank[PLAN_ITEMS];
     int key[PLAN_ITEMS];
 #pragma unroll
     for (int r = 0; r < PLAN_ITEMS; ++r) {
-        const int64_t i = base + r * PLAN_THREADS + threadIdx.x;
+        const int64_t i = base + r * PLAN_THREADS + tid;
         key[r] = -1;
         if (i < a.N) {
             key[r] = plan_key(a, i);
@@ -425,20 +452,44 @@ __global__ void __launch_bounds__(PLAN_THREADS) stg_plan_tile_kernel(const PlanA
         }
     }
     __syncthreads();
-    if (threadIdx.x < PLAN_BUCKETS) start[threadIdx.x] = cnt[threadIdx.x];
+    if (tid < nb) start[tid] = cnt[tid];
     __syncthreads();
-    for (int off = 1; off < PLAN_BUCKETS; off <<= 1) {         // Hillis-Steele inclusive scan over the 256 buckets
+    for (int off = 1; off < nb; off <<= 1) {                   // Hillis-Steele inclusive scan over the buckets
         uint32_t add = 0;
-        if (threadIdx.x < PLAN_BUCKETS && (int)threadIdx.x >= off) add = start[threadIdx.x - off];
+        if (tid < nb && tid >= off) add = start[tid - off];
         __syncthreads();
-        if (threadIdx.x < PLAN_BUCKETS) start[threadIdx.x] += add;
+        if (tid < nb) start[tid] += add;
         __syncthreads();
     }
 #pragma unroll
     for (int r = 0; r < PLAN_ITEMS; ++r) {
-        const int64_t i = base + r * PLAN_THREADS + threadIdx.x;
+        const int64_t i = base + r * PLAN_THREADS + tid;
         if (key[r] >= 0) a.perm[base + (start[key[r]] - cnt[key[r]]) + rank[r]] = (uint32_t)i;   // exclusive start
     }
+}
+
+// device-class formulas evaluated per env (stg_device_terms)
+__global__ void stg_device_terms_kernel(int64_t N, const double* ctab, const uint8_t* cls, int32_t ncls, const double* m,
+                                        const double* J, const double* volt, double* tau_dl, double* tau_fl, double* k_eff) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int c = (ncls > 1 && cls) ? (int)cls[i] : 0;
+    const double* row = ctab + (c < ncls ? c : 0) * C_COUNT;
+    const int kind = (int)row[C_DEVTYPE];
+    if (tau_dl || tau_fl) {
+        V3 dl{0.0, 0.0, 0.0}, fl{0.0, 0.0, 0.0};
+        if (kind == STG_DEV_SOT) {      // sot_mram.py:186-192: tau_dl_factor*J*cross(sigma, m), tau_fl_factor*J*sigma
+            const V3 mm{m[i], m[N + i], m[2 * N + i]}, sg{row[C_SIGX], row[C_SIGY], row[C_SIGZ]};
+            const V3 sxm = cross(sg, mm);
+            const double a = row[C_SOT_DL] * J[i], b = row[C_SOT_FL] * J[i];
+            dl = V3{a * sxm.x, a * sxm.y, a * sxm.z};
+            fl = V3{b * sg.x, b * sg.y, b * sg.z};
+        }
+        if (tau_dl) { tau_dl[i] = dl.x; tau_dl[N + i] = dl.y; tau_dl[2 * N + i] = dl.z; }
+        if (tau_fl) { tau_fl[i] = fl.x; tau_fl[N + i] = fl.y; tau_fl[2 * N + i] = fl.z; }
+    }
+    if (k_eff)
+        k_eff[i] = (kind == STG_DEV_VCMA) ? vcma_keff(volt[i], row[C_KU], row[C_VCMA_XI], row[C_VCMA_TD2], row[C_VCMA_VBD]) : row[C_KU];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -494,6 +545,9 @@ static int check_cfg(const stg_config* c) {
     if (!(c->max_current > 0) || !(c->max_duration > 0)) return fail(STG_E_INVALID, "cfg.max_current/max_duration must be positive");
     if (c->solver == STG_SOLVER_RK45 && (!(c->rtol > 0) || !(c->atol >= 0))) return fail(STG_E_INVALID, "cfg.rtol/atol invalid");
     if (c->solver == STG_SOLVER_RK45 && c->max_attempts < 1) return fail(STG_E_INVALID, "cfg.max_attempts must be >= 1");
+    if (c->torque_model < 0 || c->torque_model > 1) return fail(STG_E_INVALID, "cfg.torque_model must be 0 or 1");
+    if (c->torque_model == 1 && c->solver == STG_SOLVER_RK45)
+        return fail(STG_E_INVALID, "the device-physics torque model is implemented for the fixed-step solvers (rk4, euler)");
     return STG_OK;
 }
 
@@ -573,6 +627,13 @@ static void derive_class(const stg_device_params& p, const stg_config& cfg, doub
     r[C_RSERIES] = p.r_series;
     r[C_DEVTYPE] = (double)p.dev_type;
     r[C_VALID] = p.params_valid ? 1.0 : 0.0;
+    r[C_SOT_DL] = p.sot_tau_dl; r[C_SOT_FL] = p.sot_tau_fl;
+    r[C_SIGX] = p.sot_sigma[0]; r[C_SIGY] = p.sot_sigma[1]; r[C_SIGZ] = p.sot_sigma[2];
+    r[C_KU] = p.ku;
+    r[C_VCMA_XI] = p.vcma_xi;
+    r[C_VCMA_TD2] = p.vcma_td * p.vcma_td;                                       // dielectric_thickness**2, vcma_mram.py:139
+    r[C_VCMA_VBD] = p.vcma_vbd;
+    r[C_MU0MS] = mu0 * p.ms;
 }
 
 int stg_set_params(stg_ctx* ctx, const stg_device_params* table, int32_t n_classes, const uint8_t* cls) {
@@ -629,23 +690,29 @@ int stg_reset(stg_ctx* ctx, const uint8_t* mask, const double* init_m, const dou
 }
 
 extern "C++" {
-template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z>
+template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, bool DEVPHYS>
 static void launch_step(const StepArgs& a, int act_f64, hipStream_t st) {
     if (act_f64)
-        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, double>), grid_for(a.N), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, double>), grid_for(a.N), dim3(64), 0, st, a);
     else
-        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, float>), grid_for(a.N), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, float>), grid_for(a.N), dim3(64), 0, st, a);
 }
-template <int SOLVER, bool AXIS_Z>
+template <int SOLVER, bool AXIS_Z, bool DEVPHYS>
 static void dispatch_step2(const StepArgs& a, bool thermal, bool multi, int act_f64, hipStream_t st) {
-    if (thermal) { if (multi) launch_step<SOLVER, true, true, AXIS_Z>(a, act_f64, st); else launch_step<SOLVER, true, false, AXIS_Z>(a, act_f64, st); }
-    else { if (multi) launch_step<SOLVER, false, true, AXIS_Z>(a, act_f64, st); else launch_step<SOLVER, false, false, AXIS_Z>(a, act_f64, st); }
+    if (thermal) { if (multi) launch_step<SOLVER, true, true, AXIS_Z, DEVPHYS>(a, act_f64, st); else launch_step<SOLVER, true, false, AXIS_Z, DEVPHYS>(a, act_f64, st); }
+    else { if (multi) launch_step<SOLVER, false, true, AXIS_Z, DEVPHYS>(a, act_f64, st); else launch_step<SOLVER, false, false, AXIS_Z, DEVPHYS>(a, act_f64, st); }
 }
-// axis_z selects the easy-axis = z specialisation of the RHS (Simple: e = +z; LLGS: raw axis and demag along z)
+// axis_z selects the easy-axis = z specialisation of the RHS (Simple: e = +z; LLGS: raw axis and demag along z);
+// devphys the opt-in device-physics torque model (fixed-step solvers only)
 template <int SOLVER>
-static void dispatch_step(const StepArgs& a, bool thermal, bool multi, bool axis_z, int act_f64, hipStream_t st) {
-    if (axis_z) dispatch_step2<SOLVER, true>(a, thermal, multi, act_f64, st);
-    else dispatch_step2<SOLVER, false>(a, thermal, multi, act_f64, st);
+static void dispatch_step(const StepArgs& a, bool thermal, bool multi, bool axis_z, bool devphys, int act_f64, hipStream_t st) {
+    if (SOLVER != STG_SOLVER_RK45 && devphys) {
+        if (axis_z) dispatch_step2<SOLVER, true, true>(a, thermal, multi, act_f64, st);
+        else dispatch_step2<SOLVER, false, true>(a, thermal, multi, act_f64, st);
+    } else {
+        if (axis_z) dispatch_step2<SOLVER, true, false>(a, thermal, multi, act_f64, st);
+        else dispatch_step2<SOLVER, false, false>(a, thermal, multi, act_f64, st);
+    }
 }
 }  // extern "C++"
 
@@ -673,6 +740,8 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
         pa.max_current = ctx->cfg.max_current; pa.max_duration = ctx->cfg.max_duration;
         pa.done = ctx->s.done; pa.skip_done = (ctx->cfg.skip_done && !autoreset) ? 1 : 0;
         pa.perm = ctx->perm;
+        pa.cls = ctx->cls; pa.ctab = ctx->ctab;
+        pa.by_kind = (ctx->cfg.torque_model == 1 && ctx->ncls > 1 && ctx->cls) ? 1 : 0;
         const dim3 g((unsigned)((ctx->N + TILE_ENVS - 1) / TILE_ENVS));
         hipLaunchKernelGGL(stg_plan_tile_kernel, g, dim3(PLAN_THREADS), 0, st, pa);
         a.perm = ctx->perm;
@@ -682,10 +751,11 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
     // the Simple solver only draws a thermal field when temperature > 0 (simple_solver.py:321,378)
     const bool thermal = ctx->cfg.thermal && ctx->cfg.temperature > 0;
     const bool multi = ctx->ncls > 1;
+    const bool devphys = ctx->cfg.torque_model == 1;
     switch (ctx->cfg.solver) {
-        case STG_SOLVER_RK4: dispatch_step<STG_SOLVER_RK4>(a, thermal, multi, ctx->axis_z, act_f64, st); break;
-        case STG_SOLVER_EULER: dispatch_step<STG_SOLVER_EULER>(a, thermal, multi, ctx->axis_z, act_f64, st); break;
-        default: dispatch_step<STG_SOLVER_RK45>(a, ctx->cfg.thermal != 0, multi, ctx->axis_z_llgs, act_f64, st); break;
+        case STG_SOLVER_RK4: dispatch_step<STG_SOLVER_RK4>(a, thermal, multi, ctx->axis_z, devphys, act_f64, st); break;
+        case STG_SOLVER_EULER: dispatch_step<STG_SOLVER_EULER>(a, thermal, multi, ctx->axis_z, devphys, act_f64, st); break;
+        default: dispatch_step<STG_SOLVER_RK45>(a, ctx->cfg.thermal != 0, multi, ctx->axis_z_llgs, false, act_f64, st); break;
     }
     HIP_TRY(hipGetLastError());
     return STG_OK;
@@ -797,6 +867,19 @@ int stg_set_state(stg_ctx* ctx, const double* m, const double* target, const dou
     if (rng_step) HIP_TRY(hipMemcpyAsync(ctx->s.rng, rng_step, N * 4, hipMemcpyDeviceToDevice, st));
     if (done) HIP_TRY(hipMemcpyAsync(ctx->s.done, done, N, hipMemcpyDeviceToDevice, st));
     if (m && target) ctx->have_state = true;
+    return STG_OK;
+}
+
+int stg_device_terms(stg_ctx* ctx, const double* m, const double* J, const double* volt, double* tau_dl, double* tau_fl,
+                     double* k_eff, void* stream) {
+    if (!ctx) return fail(STG_E_INVALID, "ctx is NULL");
+    if (!ctx->have_params) return fail(STG_E_STATE, "stg_set_params must precede stg_device_terms");
+    if ((tau_dl || tau_fl) && (!m || !J)) return fail(STG_E_INVALID, "m and J are required for the SOT torques");
+    if (k_eff && !volt) return fail(STG_E_INVALID, "volt is required for K_eff");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(stg_device_terms_kernel, dim3((unsigned)((ctx->N + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       ctx->N, ctx->ctab, ctx->cls, ctx->ncls, m, J, volt, tau_dl, tau_fl, k_eff);
+    HIP_TRY(hipGetLastError());
     return STG_OK;
 }
 

@@ -52,6 +52,13 @@ enum ClassConst : int {
     C_RSERIES,
     C_DEVTYPE,                 // STG_DEV_* as double
     C_VALID,                   // validate_parameters outcome as double (0/1)
+    // opt-in device-physics torque model
+    C_SOT_DL, C_SOT_FL,        // tau_dl_factor, tau_fl_factor                 sot_mram.py:61-72
+    C_SIGX, C_SIGY, C_SIGZ,    // sigma = z x j_hat                            sot_mram.py:183-186
+    C_KU,                      // uniaxial anisotropy K
+    C_VCMA_XI, C_VCMA_TD2,     // vcma_coefficient, dielectric_thickness**2    vcma_mram.py:136-139
+    C_VCMA_VBD,                // breakdown_voltage                            vcma_mram.py:132
+    C_MU0MS,                   // mu_0 * ms (denominator of h_k)
     C_COUNT
 };
 
@@ -191,12 +198,12 @@ struct LlgsK {              // A6 constants
 // 31 fp64 instructions (T = 0 K) instead of 42 for the literal form; every intermediate stays at or below the
 // magnitude of the reference's own intermediates, so overflow happens at the same sub-step.
 template <bool THERMAL, bool AXIS_Z>
-__device__ __forceinline__ V3 simple_rhs(const V3& m, const SimpleK& k, double kJ, const V3& z) {
+__device__ __forceinline__ V3 simple_rhs(const V3& m, const SimpleK& k, double hk, double kJ, const V3& z) {
     if (AXIS_Z) {
         // easy axis = +z exactly (every factory default, device_factory.py:129-172): t = (my, -mx, 0), H = (0, 0, hz),
         // so the products with the axis' zero components drop out -- 14 fp64 instructions at T = 0 K.  (They only
         // differ from the general form when a factor is already inf/NaN, where both forms end non-finite.)
-        const double hz = __builtin_fma(k.hk, m.z, -k.ms * m.z);
+        const double hz = __builtin_fma(hk, m.z, -k.ms * m.z);
         V3 p;
         if (THERMAL) {
             const V3 h{k.hs * z.x, k.hs * z.y, __builtin_fma(k.hs, z.z, hz)};
@@ -216,7 +223,7 @@ __device__ __forceinline__ V3 simple_rhs(const V3& m, const SimpleK& k, double k
         return V3{-k.geff * r.x, -k.geff * r.y, -k.geff * r.z};
     }
     const V3 t = cross(m, k.e);
-    const double c = k.hk * dot(m, k.e);
+    const double c = hk * dot(m, k.e);
     const double d = -k.ms * m.z;
     V3 p;
     if (THERMAL) {
@@ -231,6 +238,42 @@ __device__ __forceinline__ V3 simple_rhs(const V3& m, const SimpleK& k, double k
     const V3 r{__builtin_fma(m.y, w.z, __builtin_fma(-m.z, w.y, p.x)), __builtin_fma(m.z, w.x, __builtin_fma(-m.x, w.z, p.y)),
                __builtin_fma(m.x, w.y, __builtin_fma(-m.y, w.x, p.z))};
     return V3{-k.geff * r.x, -k.geff * r.y, -k.geff * r.z};
+}
+
+// ---- opt-in device-physics torque model (BASELINE config 4 "divergent torque terms") -------------------
+// The reference env integrates the same type-agnostic RHS for every device type; its device classes carry torque
+// formulas the env never calls.  With cfg.torque_model = 1 the Simple RHS uses them per lane:
+//   STT  : Slonczewski term of the reference RHS (unchanged)
+//   SOT  : no Slonczewski term; + [tau_dl J (sigma x m) + tau_fl J sigma] / (ms V)      SOTMRAMDevice.compute_spin_torque
+//   VCMA : Slonczewski term, with H_k from K_eff(V), V = J R(m) A while the pulse is on    VCMAMRAMDevice._compute_effective_anisotropy
+// (the 1/(ms V) normalisation is the one the reference applies to its own torque vector, simple_solver.py:330).
+// Lanes differ only in coefficients (predication, no divergent control flow); `any_sot` is wave-uniform (ballot), so
+// wavefronts without a SOT lane skip the extra cross product -- and the lane schedule groups lanes by type.
+struct DevTorque {
+    double sdl, sfl;      // tau_dl J/(ms V), tau_fl J/(ms V) for SOT lanes, else 0
+    V3 sigma;
+    double hk_pulse;      // H_k while the pulse is on (VCMA: from K_eff(V)); = hk for other types
+    bool any_sot;         // wave-uniform
+};
+
+// K_eff(V) of vcma_mram.py:122-147
+__device__ __forceinline__ double vcma_keff(double volt, double ku, double xi, double td2, double vbd) {
+    const double v = volt < -vbd ? -vbd : (volt > vbd ? vbd : volt);
+    const double keff = ku + (-xi * fabs(v) / td2);
+    return fmax(keff, -0.5 * ku);
+}
+
+template <bool THERMAL, bool AXIS_Z, bool DEVPHYS>
+__device__ __forceinline__ V3 simple_stage(const V3& m, const SimpleK& k, double kJ, const V3& z, const DevTorque& dv,
+                                           bool on) {
+    if (!DEVPHYS) return simple_rhs<THERMAL, AXIS_Z>(m, k, k.hk, kJ, z);
+    V3 f = simple_rhs<THERMAL, AXIS_Z>(m, k, on ? dv.hk_pulse : k.hk, kJ, z);
+    if (dv.any_sot) {
+        const double a = on ? dv.sdl : 0.0, b = on ? dv.sfl : 0.0;
+        const V3 sxm = cross(dv.sigma, m);
+        f = V3{f.x + (a * sxm.x + b * dv.sigma.x), f.y + (a * sxm.y + b * dv.sigma.y), f.z + (a * sxm.z + b * dv.sigma.z)};
+    }
+    return f;
 }
 
 // SimpleLLGSSolver._validate_magnetization (simple_solver.py:208-229).
@@ -284,10 +327,10 @@ struct Recorder {
 };
 
 // A3 + A4 + A5: RobustLLGSSolver.solve -> SimpleLLGSSolver.solve, METHOD 0 = rk4, 1 = euler.
-template <int METHOD, bool THERMAL, bool RECORD, bool AXIS_Z>
+template <int METHOD, bool THERMAL, bool RECORD, bool AXIS_Z, bool DEVPHYS>
 __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double T, const SimpleK& k, double pol,
                                                  double msv, bool class_valid, double temperature, double max_step,
-                                                 const RngKey& rk, const Recorder& rec) {
+                                                 const RngKey& rk, const Recorder& rec, const DevTorque& dv) {
     SolveOut o{m0, 0, 0, 0, false};
     // robust_solver.py:152-190 (_validate_inputs); any failure ends in the fallback result (:140-150)
     if (validation_rejects(m0) || !(T > 0.0) || !class_valid || !(temperature > 0.0)) return o;
@@ -310,8 +353,9 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
     // sub-step's k2/k3/k4 stages can land an ulp beyond T and see J = 0, so only that one is tested,
     // in exactly the reference's roundings.
     const double t_last = mul_x((double)(n - 1), dt);
-    const double kJ2_last = (add_x(t_last, mul_x(dt, 0.5)) <= T) ? kJ : 0.0;
-    const double kJ4_last = (add_x(t_last, dt) <= T) ? kJ : 0.0;
+    const bool on2_last = add_x(t_last, mul_x(dt, 0.5)) <= T, on4_last = add_x(t_last, dt) <= T;
+    const double kJ2_last = on2_last ? kJ : 0.0;
+    const double kJ4_last = on4_last ? kJ : 0.0;
     bool fail = false;
     const V3 zero{0.0, 0.0, 0.0};
     NormalStream ns;
@@ -320,24 +364,25 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
     for (int i = 0; i < n; ++i) {
         const bool last = (i == n - 1);
         const double kJ2 = last ? kJ2_last : kJ, kJ4 = last ? kJ4_last : kJ;
+        const bool on2 = !last || on2_last, on4 = !last || on4_last;
         V3 mn;
         if (METHOD == 1) {
             V3 z0 = zero;
             if (THERMAL) z0 = (i & 1) ? ns.draw3_odd() : ns.draw3_even();
-            const V3 f = simple_rhs<THERMAL, AXIS_Z>(m, k, kJ, z0);
+            const V3 f = simple_stage<THERMAL, AXIS_Z, DEVPHYS>(m, k, kJ, z0, dv, true);
             mn = V3{m.x + dt * f.x, m.y + dt * f.y, m.z + dt * f.z};      // simple_solver.py:275-276
         } else {
             V3 z0 = zero, z1 = zero, z2 = zero, z3 = zero;
             if (THERMAL) {   // 12 normals = 6 Box-Muller pairs per sub-step
                 z0 = ns.draw3_even(); z1 = ns.draw3_odd(); z2 = ns.draw3_even(); z3 = ns.draw3_odd();
             }
-            const V3 f1 = simple_rhs<THERMAL, AXIS_Z>(m, k, kJ, z0);
+            const V3 f1 = simple_stage<THERMAL, AXIS_Z, DEVPHYS>(m, k, kJ, z0, dv, true);
             const V3 y2{m.x + half_dt * f1.x, m.y + half_dt * f1.y, m.z + half_dt * f1.z};
-            const V3 f2 = simple_rhs<THERMAL, AXIS_Z>(y2, k, kJ2, z1);
+            const V3 f2 = simple_stage<THERMAL, AXIS_Z, DEVPHYS>(y2, k, kJ2, z1, dv, on2);
             const V3 y3{m.x + half_dt * f2.x, m.y + half_dt * f2.y, m.z + half_dt * f2.z};
-            const V3 f3 = simple_rhs<THERMAL, AXIS_Z>(y3, k, kJ2, z2);
+            const V3 f3 = simple_stage<THERMAL, AXIS_Z, DEVPHYS>(y3, k, kJ2, z2, dv, on2);
             const V3 y4{m.x + dt * f3.x, m.y + dt * f3.y, m.z + dt * f3.z};
-            const V3 f4 = simple_rhs<THERMAL, AXIS_Z>(y4, k, kJ4, z3);
+            const V3 f4 = simple_stage<THERMAL, AXIS_Z, DEVPHYS>(y4, k, kJ4, z3, dv, on4);
             // m + (k1 + 2 k2 + 2 k3 + k4)/6 with k = dt*f                  simple_solver.py:290-295
             mn = V3{m.x + sixth_dt * ((f1.x + 2.0 * f2.x) + (2.0 * f3.x + f4.x)),
                     m.y + sixth_dt * ((f1.y + 2.0 * f2.y) + (2.0 * f3.y + f4.y)),

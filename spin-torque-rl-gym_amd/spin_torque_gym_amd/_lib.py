@@ -24,7 +24,7 @@ class StgConfig(C.Structure):
         ("n_targets", C.c_int32), ("max_current", C.c_double), ("max_duration", C.c_double),
         ("success_threshold", C.c_double), ("energy_penalty_weight", C.c_double),
         ("targets", (C.c_double * 3) * STG_MAX_TARGETS), ("seed", C.c_uint64), ("max_attempts", C.c_int64),
-        ("skip_done", C.c_int32), ("lane_sort", C.c_int32),
+        ("skip_done", C.c_int32), ("torque_model", C.c_int32), ("reserved", C.c_int32), ("lane_sort", C.c_int32),
     ]
 
 
@@ -33,7 +33,9 @@ class StgDeviceParams(C.Structure):
         ("damping", C.c_double), ("ms", C.c_double), ("ku", C.c_double), ("volume", C.c_double),
         ("polarization", C.c_double), ("easy_axis", C.c_double * 3), ("demag", C.c_double * 3),
         ("a_ex", C.c_double), ("area", C.c_double), ("r_p", C.c_double), ("r_ap", C.c_double),
-        ("ref_m", C.c_double * 3), ("r_series", C.c_double), ("dev_type", C.c_int32), ("params_valid", C.c_int32),
+        ("ref_m", C.c_double * 3), ("r_series", C.c_double), ("sot_tau_dl", C.c_double), ("sot_tau_fl", C.c_double),
+        ("sot_sigma", C.c_double * 3), ("vcma_xi", C.c_double), ("vcma_td", C.c_double), ("vcma_vbd", C.c_double),
+        ("dev_type", C.c_int32), ("params_valid", C.c_int32),
     ]
 
 
@@ -50,6 +52,7 @@ SYMBOLS = {
     "stg_step_many": (C.c_int, [_VP, C.c_int32, _VP, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "stg_get_state": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "stg_set_state": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "stg_device_terms": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "stg_get_counters": (C.c_int, [_VP, C.POINTER(C.c_uint64), C.c_int32]),
     "stg_solve": (C.c_int, [_VP, _VP, _VP, _VP, C.c_uint32, _VP, _VP, _VP, _VP]),
     "stg_solve_traj": (C.c_int, [_VP, _VP, _VP, _VP, C.c_uint32, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),

@@ -34,6 +34,7 @@ class EnvConfig:
     seed: int = 0
     max_attempts: int = 200_000               # RK45 attempts per solve before giving up (a 5 ns pulse needs ~10 000)
     skip_done: bool = False
+    torque_model: str = "reference"           # 'reference' (the env's type-agnostic RHS) | 'device' (opt-in)
     lane_sort: Optional[bool] = None          # duration-sorted lane schedule: None = automatic, True/False = force
 
     def to_abi(self) -> "_lib.StgConfig":
@@ -56,6 +57,9 @@ class EnvConfig:
         c.seed = int(self.seed) & 0xFFFFFFFFFFFFFFFF
         c.max_attempts = int(self.max_attempts)
         c.skip_done = int(bool(self.skip_done))
+        if self.torque_model not in ("reference", "device"):
+            raise ValueError("torque_model must be 'reference' or 'device'")
+        c.torque_model = int(self.torque_model == "device")
         c.lane_sort = 0 if self.lane_sort is None else (1 if self.lane_sort else -1)
         return c
 
@@ -245,6 +249,20 @@ class HipBackend:
                                           _ptr(npts), _ptr(succ), self._stream()))
         self._keep = (m0, J, T)
         return out
+
+    def device_terms(self, m, J, volt):
+        """Device-class formulas per env: (tau_dl [3,N], tau_fl [3,N], k_eff [N]) for m [3,N], J [N], volt [N]."""
+        n, dev = self.n, self.device
+        m = self._dev(m, torch.float64, (3, n))
+        J = self._dev(J, torch.float64, (n,))
+        volt = self._dev(volt, torch.float64, (n,))
+        dl = torch.empty((3, n), dtype=torch.float64, device=dev)
+        fl = torch.empty((3, n), dtype=torch.float64, device=dev)
+        ke = torch.empty(n, dtype=torch.float64, device=dev)
+        _lib.check(self.lib.stg_device_terms(self._ctx, _ptr(m), _ptr(J), _ptr(volt), _ptr(dl), _ptr(fl), _ptr(ke),
+                                             self._stream()))
+        self._keep = (m, J, volt)
+        return dl, fl, ke
 
     def counters(self, reset=False):
         """On-device metrics: dict(env_steps, work_units, noop_steps).  Synchronises the device."""

@@ -308,6 +308,17 @@ def flatten_params(device: BaseSpintronicDevice) -> "_lib.StgDeviceParams":
     p.r_ap = d.get("resistance_antiparallel", 2e3)
     p.ref_m[:] = [float(x) for x in np.asarray(d.get("reference_magnetization", [0, 0, 1]), dtype=float)]
     p.r_series = device.series_resistance() if isinstance(device, SOTMRAMDevice) else 0.0
+    # coefficients of the opt-in device-physics torque model (stg_config.torque_model = 1)
+    p.sot_tau_dl = p.sot_tau_fl = 0.0
+    p.sot_sigma[:] = [0.0, 1.0, 0.0]
+    p.vcma_xi, p.vcma_td, p.vcma_vbd = 0.0, 1e-9, 2.0
+    if isinstance(device, SOTMRAMDevice):
+        p.sot_tau_dl, p.sot_tau_fl = device.tau_dl_factor, device.tau_fl_factor
+        j_hat = np.asarray(d.get("current_direction", [1.0, 0.0, 0.0]), dtype=float)
+        j_hat = j_hat / np.linalg.norm(j_hat)
+        p.sot_sigma[:] = [float(x) for x in np.cross(np.array([0.0, 0.0, 1.0]), j_hat)]      # sot_mram.py:183-186
+    if isinstance(device, VCMAMRAMDevice):
+        p.vcma_xi, p.vcma_td, p.vcma_vbd = device.vcma_coefficient, device.dielectric_thickness, device.breakdown_voltage
     if device.device_type not in _lib.DEV_TYPES:
         raise ValueError(f"device type '{device.device_type}' is not supported on the GPU step path")
     p.dev_type = _lib.DEV_TYPES[device.device_type]

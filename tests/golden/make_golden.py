@@ -418,7 +418,39 @@ def G11():
          success=rows[:, 4].astype(bool), m_final=rows[:, 5:8], n_steps=rows[:, 8].astype(int))
 
 
-ALL = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11)
+def G12():
+    """device_terms: SOTMRAMDevice.compute_spin_torque and VCMAMRAMDevice._compute_effective_anisotropy (the device-class
+    formulas the env never calls; they pin the opt-in device-physics torque extension)."""
+    rng = np.random.default_rng(1212)
+    fac = DeviceFactory()
+    ms = unit_rows(rng, 48)
+    Js = rng.uniform(-2e6, 2e6, 48)
+    out = {"m": ms, "J": Js}
+    for tag, over in (("default", {}), ("custom", dict(spin_hall_angle=0.3, heavy_metal_thickness=4e-9, interface_transparency=0.6,
+                                                        field_like_efficiency=0.15, damping_like_efficiency=0.25, thickness=1.2e-9))):
+        p = fac.get_default_parameters("sot_mram")
+        p.update(over)
+        dev = fac.create_device("sot_mram", p)
+        dl, fl = zip(*[dev.compute_spin_torque(float(J), m.copy()) for m, J in zip(ms, Js)])
+        out[f"sot_{tag}_tau_dl"] = np.array(dl)
+        out[f"sot_{tag}_tau_fl"] = np.array(fl)
+        out[f"sot_{tag}_factors"] = np.array([dev.tau_dl_factor, dev.tau_fl_factor])
+    d2 = fac.create_device("sot_mram", fac.get_default_parameters("sot_mram"))
+    dirn = np.array([1.0, 1.0, 0.0])
+    dl, fl = zip(*[d2.compute_spin_torque(float(J), m.copy(), dirn) for m, J in zip(ms, Js)])
+    out["sot_dir110_tau_dl"], out["sot_dir110_tau_fl"] = np.array(dl), np.array(fl)
+    volts = np.concatenate([np.linspace(-3, 3, 25), [0.0, 1e-3, 2.0, -2.0, 10.0]])
+    out["volts"] = volts
+    for tag, over in (("default", {}), ("custom", dict(vcma_coefficient=60e-6, dielectric_thickness=1.4e-9, breakdown_voltage=1.5,
+                                                        uniaxial_anisotropy=0.9e6))):
+        p = fac.get_default_parameters("vcma_mram")
+        p.update(over)
+        dev = fac.create_device("vcma_mram", p)
+        out[f"vcma_{tag}_keff"] = np.array([dev._compute_effective_anisotropy(float(v)) for v in volts])
+    save("G12_device_terms", **out)
+
+
+ALL = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11, G12=G12)
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

@@ -22,7 +22,8 @@ def oracle_config(cfg):
                               gamma=cfg.gamma, max_step=cfg.max_step, rtol=cfg.rtol, atol=cfg.atol,
                               max_steps=cfg.max_steps, max_current=cfg.max_current, max_duration=cfg.max_duration,
                               success_threshold=cfg.success_threshold, energy_penalty_weight=cfg.energy_penalty_weight,
-                              seed=cfg.seed, max_attempts=cfg.max_attempts)
+                              seed=cfg.seed, max_attempts=cfg.max_attempts,
+                              torque_model=int(getattr(cfg, "torque_model", "reference") == "device"))
 
 
 def oracle_params(table):

@@ -628,3 +628,45 @@ def test_kernel_variant_matrix_vs_oracle(stg, solver):
                 assert np.allclose(o1, o2, rtol=3e-7, atol=1e-9) and np.allclose(r1, r2, rtol=1e-9, atol=1e-9), tag
                 worst = max(worst, np.abs(m1 - m2).max())
     print(solver, "variant matrix worst |dm| =", worst)
+
+
+def test_g12_device_terms_kernel_vs_reference_formulas(stg, golden):
+    from test_oracle_golden import G12_SOT, G12_VCMA
+    g = golden("G12_device_terms")
+    n = len(g["m"])
+    for tag, over in G12_SOT.items():
+        d = sot_default_params(**over)
+        b = _backend(stg, n, [_flat(stg, d, "sot_mram")], solver="rk4")
+        dl, fl, _ = b.device_terms(torch.tensor(g["m"].T.copy()), torch.tensor(g["J"].copy()), torch.zeros(n, dtype=torch.float64))
+        # FMA contraction inside sigma x m: agreement to rounding of the vector's magnitude
+        scale = np.abs(g[f"sot_{tag}_tau_dl"]).max()
+        assert np.allclose(dl.cpu().numpy().T, g[f"sot_{tag}_tau_dl"], rtol=1e-14, atol=1e-15 * scale), tag
+        assert np.allclose(fl.cpu().numpy().T, g[f"sot_{tag}_tau_fl"], rtol=1e-14, atol=0), tag
+        b.close()
+    nv = len(g["volts"])
+    for tag, over in G12_VCMA.items():
+        b = _backend(stg, nv, [_flat(stg, vcma_default_params(**over), "vcma_mram")], solver="rk4")
+        _, _, ke = b.device_terms(torch.zeros((3, nv), dtype=torch.float64), torch.zeros(nv, dtype=torch.float64),
+                                  torch.tensor(g["volts"].copy()))
+        assert np.array_equal(ke.cpu().numpy(), g[f"vcma_{tag}_keff"]), tag
+        b.close()
+
+
+@pytest.mark.parametrize("thermal", [False, True])
+def test_device_torque_model_mixed_batch_vs_oracle(stg, thermal):
+    """BASELINE config 4 shape: mixed STT/SOT/VCMA batch with the opt-in device-physics torque terms (per-lane
+    coefficients, type-grouped lane schedule) against the oracle's restatement; reference mode differs."""
+    n = 3072
+    cls = np.random.default_rng(3).integers(0, 3, n).astype(np.uint8)
+    types = ["stt_mram", "sot_mram", "vcma_mram"]
+    params = [stt_default_params(volume=8.75e-11),
+              sot_default_params(polarization=0.7, volume=8.75e-11, current_direction=np.array([1.0, 0.3, 0.0])),
+              vcma_default_params(polarization=0.6, volume=5e-11, vcma_coefficient=3e-13, easy_axis=np.array([0.1, 0.0, 1.0]))]
+    common = dict(device_type=types, device_params=params, class_index=cls, include_thermal_fluctuations=thermal,
+                  solver="rk4", seed=6)
+    outs = _run_pair(stg, n, 2, _uniform_actions(2e6, 1e-10, 4e-10), torque_model="device", **common)
+    _compare(outs, TOL_RK4 if not thermal else 1e-9)
+    ref_mode = _run_pair(stg, n, 1, _uniform_actions(2e6, 1e-10, 4e-10), **common)
+    dm = np.abs(outs[0][1]["m"] - ref_mode[0][1]["m"]).max(axis=0)
+    assert np.all(dm[cls == 0] == 0.0)                       # STT lanes: identical bits in both models
+    assert dm[cls == 1].max() > 1e-6 and dm[cls == 2].max() > 1e-6
