@@ -141,6 +141,49 @@ def run_config(n_local, solver, thermal, steps, warmup, rank, world, device_inde
                 env_steps=c["env_steps"], work_units=c["work_units"], noop_steps=c["noop_steps"])
 
 
+def run_array_config(n, mode, steps, device_index, size=(4, 4)):
+    """SpinTorqueArray-v0 (SURVEY 8f #2): N independent R x C arrays, random actions; this kernel is HBM-shaped."""
+    import spin_torque_gym_amd as stg
+    env = stg.SpinTorqueArrayVecEnv(n, size, action_mode=mode, seed=3, device_index=device_index, max_steps=10**6,
+                                    success_threshold=2.0)
+    env.reset(seed=1)
+    dev = env.backend.device
+    g = torch.Generator(device="cpu").manual_seed(5)
+    ndev = size[0] * size[1]
+    a_dim = 2 if mode == "global" else 3
+    acts = torch.empty((steps + 2, a_dim, n), dtype=torch.float32)
+    if mode == "global":
+        acts[:, 0] = (torch.rand((steps + 2, n), generator=g) * 2 - 1) * 2e6
+        acts[:, 1] = (torch.rand((steps + 2, n), generator=g) * 2 - 1) * 2e6      # read as the current (reference quirk)
+    else:
+        acts[:, 0] = torch.rand((steps + 2, n), generator=g) * ndev
+        acts[:, 1] = (torch.rand((steps + 2, n), generator=g) * 2 - 1) * 2e6
+        acts[:, 2] = 1e-10 + torch.rand((steps + 2, n), generator=g) * 9e-10
+    acts = acts.to(dev)
+    for k in range(2):
+        env.backend.step(acts[k])
+    torch.cuda.synchronize(dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ev[k][0].record()
+        env.backend.step(acts[k + 2])
+        ev[k][1].record()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    ms = float(np.mean([x.elapsed_time(y) for x, y in ev]))
+    env.close()
+    affected = {"individual": 1, "row": size[1], "column": size[0], "global": ndev}[mode]
+    # algorithmic bytes per array-step: pattern + target + state + action read; addressed cells, obs, reward, flags, state written
+    b = (ndev * 24 * 2 + 12 + 4 * a_dim) + (affected * 24 + ndev * 24 + 4 + 2 + 12 + 16)
+    gbs = b * n / (ms * 1e-3) / 1e9
+    return {"workload": f"SpinTorqueArray-v0: {n} arrays of {size[0]}x{size[1]} STT cells, action_mode={mode}, dipolar coupling",
+            "value": round(n * steps / wall, 1), "unit": "array-steps/s", "ms_per_step": round(wall / steps * 1e3, 4),
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "kernel": "stg_array_step_kernel",
+                         "kernel_ms_avg": round(ms, 4), "bytes_per_array_step": b}}
+
+
 def _sharded_step(env, a):
     env.local.backend.step(a, autoreset=True)
     env._gather(unpack=False)
@@ -287,6 +330,8 @@ def main():
             st = max(3, args.steps // 2)
             also.append({"workload": name, "value": round(n * st / m["wall_s"], 1), "unit": "env-steps/s",
                          "ms_per_step": round(m["wall_s"] / st * 1e3, 4), "roofline": roofline(m, n, st, solver, mixed)})
+        for mode in ("individual", "global"):
+            also.append(run_array_config(262144, mode, max(3, args.steps // 2), local_rank))
         out["also"] = also
     if rank == 0 and world == 1 and args.cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.solver, args.thermal, args.cpu_seconds)

@@ -121,6 +121,8 @@ typedef struct {
     double vcma_xi;                 /* VCMA: 'vcma_coefficient' */
     double vcma_td;                 /* VCMA: 'dielectric_thickness' */
     double vcma_vbd;                /* VCMA: 'breakdown_voltage' */
+    double shape_demag[3];          /* SOT/VCMA: demag factors of compute_effective_field from 'aspect_ratio'
+                                       (sot_mram.py:114-132, vcma_mram.py:149-166); zeros for STT.  Array env only. */
     int32_t dev_type;               /* STG_DEV_* : selects the compute_resistance form */
     int32_t params_valid;           /* outcome of validate_parameters(params,'stt_mram') (utils/validation.py:176-234),
                                        evaluated by the host mirror; 0 -> every solve falls back (no-op) */
@@ -216,6 +218,44 @@ int stg_thermal_strength(stg_ctx* ctx, int32_t cls, double* out);
 /* Dumps the standard normals the kernels would draw for RHS calls call0..call0+n_calls-1 of env step `env_step`:
  * z [dev] double[n_calls][3][N].  Diagnostic entry used by the distribution tests. */
 int stg_thermal_normals(stg_ctx* ctx, uint32_t env_step, uint32_t call0, int32_t n_calls, double* z, void* stream);
+
+/* ---- SpinTorqueArray-v0 (spin_torque_gym/envs/array_env.py) --------------------------------- */
+
+typedef struct stg_array_ctx stg_array_ctx;
+
+/* SpinTorqueArrayEnv.__init__ keyword arguments that reach the step path (array_env.py:30-52) */
+typedef struct {
+    int32_t rows, cols;             /* array_size; rows*cols <= 64 */
+    int32_t action_mode;            /* 0 'individual' [device, J, T], 1 'row', 2 'column', 3 'global' [J, T] (:427-445) */
+    int32_t include_coupling;
+    int32_t max_steps;              /* 200 */
+    int32_t obs_mode;               /* 0 'array' (rows*cols*6 floats), 1 'vector' (rows*cols*6 + 4) (:533-557) */
+    double max_current, max_duration, success_threshold, energy_penalty_weight, temperature;
+} stg_array_config;
+
+/* n_arrays independent arrays on GPU device_id; dev = the device class of every cell (DeviceFactory.create_device per
+ * cell, array_env.py:113-120); coupling [host] double[n][n] = _compute_coupling_matrix (:301-334), may be NULL when
+ * include_coupling = 0.  env_id0: global index of the first array (device-side reset draws). */
+int stg_array_create(stg_array_ctx** out, int device_id, int64_t n_arrays, int64_t env_id0, const stg_array_config* cfg,
+                     const stg_device_params* dev, const double* coupling);
+void stg_array_destroy(stg_array_ctx* ctx);
+
+/* SpinTorqueArrayEnv.reset (array_env.py:336-360) for arrays with mask[i] != 0 (NULL: all).  init_pattern / target [dev]
+ * double[rows*cols][3][N] (options['initial_pattern'] / options['target_pattern']); NULL init_pattern: normalised normal
+ * draws on the device; NULL target: keep the current target (the +-z checkerboard of :161-170 at first).
+ * obs_out float[obs_dim][N] or NULL. */
+int stg_array_reset(stg_array_ctx* ctx, const uint8_t* mask, const double* init_pattern, const double* target,
+                    uint64_t seed, float* obs_out, void* stream);
+
+/* SpinTorqueArrayEnv.step (array_env.py:362-409) for all N arrays.  actions [dev] float[A][N], A = 3 ([index, J, T]) or
+ * 2 in 'global' mode -- where, as in the reference, action[1] is read as the current density and the duration defaults
+ * to 1 ns.  obs float[obs_dim][N]; reward float[N]; reward_f64 / energy double[N] or NULL; terminated / truncated uint8[N]. */
+int stg_array_step(stg_array_ctx* ctx, const float* actions, float* obs, float* reward, double* reward_f64, double* energy,
+                   uint8_t* terminated, uint8_t* truncated, void* stream);
+
+/* pattern, target: double[rows*cols][3][N]; total_energy double[N]; step_count int32[N]; any may be NULL */
+int stg_array_get_state(stg_array_ctx* ctx, double* pattern, double* target, double* total_energy, int32_t* step_count,
+                        void* stream);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,9 @@ _SO = os.path.join(_HERE, "_build", "libstg_oracle.so")
 
 __all__ = ["Params", "Config", "EnvState", "StepOut", "lib", "build", "make_params", "make_config",
            "simple_solve", "llgs_solve", "resistance", "thermal_strength", "env_step", "env_step_batch",
-           "thermal_normals", "parse_action", "simple_dmdt", "llgs_rhs", "DEV_TYPES", "sot_torque", "vcma_keff"]
+           "thermal_normals", "parse_action", "simple_dmdt", "llgs_rhs", "DEV_TYPES", "sot_torque", "vcma_keff",
+           "ArrayConfig", "make_array_config", "array_coupling", "ArrayEnvState", "array_step", "array_observation",
+           "device_field"]
 
 DEV_TYPES = {"stt_mram": 0, "sot_mram": 1, "vcma_mram": 2}
 
@@ -26,7 +28,14 @@ class Params(C.Structure):
                 ("a_ex", C.c_double), ("area", C.c_double), ("r_p", C.c_double), ("r_ap", C.c_double),
                 ("ref_m", C.c_double * 3), ("r_series", C.c_double), ("sot_tau_dl", C.c_double), ("sot_tau_fl", C.c_double),
                 ("sot_sigma", C.c_double * 3), ("vcma_xi", C.c_double), ("vcma_td", C.c_double), ("vcma_vbd", C.c_double),
-                ("dev_type", C.c_int32), ("params_valid", C.c_int32)]
+                ("shape_demag", C.c_double * 3), ("dev_type", C.c_int32), ("params_valid", C.c_int32)]
+
+
+class ArrayConfig(C.Structure):
+    _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("action_mode", C.c_int32), ("include_coupling", C.c_int32),
+                ("max_steps", C.c_int32), ("obs_mode", C.c_int32), ("max_current", C.c_double),
+                ("max_duration", C.c_double), ("success_threshold", C.c_double), ("energy_penalty_weight", C.c_double),
+                ("temperature", C.c_double)]
 
 
 class Config(C.Structure):
@@ -98,6 +107,16 @@ def lib():
         L.stgo_sot_torque.argtypes = [dp, C.c_double, C.POINTER(Params), dp, dp]
         L.stgo_vcma_keff.restype = C.c_double
         L.stgo_vcma_keff.argtypes = [C.c_double, C.POINTER(Params)]
+        L.stgo_array_coupling.restype = None
+        L.stgo_array_coupling.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, dp]
+        L.stgo_array_step.restype = None
+        L.stgo_array_step.argtypes = [C.POINTER(ArrayConfig), C.POINTER(Params), dp, dp, dp, dp, C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), dp, C.POINTER(C.c_uint8),
+                                      C.POINTER(C.c_uint8), dp]
+        L.stgo_array_observation.restype = None
+        L.stgo_array_observation.argtypes = [C.POINTER(ArrayConfig), dp, dp, C.c_double, C.c_int32, C.POINTER(C.c_float)]
+        L.stgo_device_field.restype = None
+        L.stgo_device_field.argtypes = [dp, C.POINTER(Params), dp]
         L.stgo_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -148,6 +167,15 @@ def make_params(device_params, device_type="stt_mram"):
     p.ref_m[:] = list(np.asarray(d.get("reference_magnetization", [0, 0, 1]), dtype=float))
     p.dev_type = DEV_TYPES[device_type]
     p.r_series = 0.0
+    # devices/sot_mram.py:114-132 (same in vcma_mram.py:149-166): demag factors from the aspect ratio
+    p.shape_demag[:] = [0.0, 0.0, 0.0]
+    if device_type in ("sot_mram", "vcma_mram"):
+        ar = d.get("aspect_ratio", 1.0)
+        if ar >= 1.0:
+            n_x, n_y = 1.0 / (1.0 + ar), ar / (1.0 + ar)
+        else:
+            n_x, n_y = ar / (1.0 + ar), 1.0 / (1.0 + ar)
+        p.shape_demag[:] = [n_x, n_y, 1.0 - n_x - n_y]
     p.sot_tau_dl = p.sot_tau_fl = 0.0
     p.sot_sigma[:] = [0.0, 1.0, 0.0]
     p.vcma_xi, p.vcma_td, p.vcma_vbd = 0.0, 1e-9, 2.0
@@ -279,6 +307,66 @@ def sot_torque(m, J, p):
 
 def vcma_keff(volt, p):
     return lib().stgo_vcma_keff(float(volt), C.byref(p))
+
+
+ARRAY_MODES = {"individual": 0, "row": 1, "column": 2, "global": 3}
+COUPLING_TYPES = {"dipolar": 0, "exchange": 1, "stray_field": 2}
+
+
+def make_array_config(rows=4, cols=4, action_mode="individual", include_coupling=True, max_steps=200, obs_mode="array",
+                      max_current=2e6, max_duration=5e-9, success_threshold=0.9, energy_penalty_weight=0.1,
+                      temperature=300.0):
+    c = ArrayConfig()
+    c.rows, c.cols, c.action_mode = rows, cols, ARRAY_MODES[action_mode]
+    c.include_coupling, c.max_steps, c.obs_mode = int(include_coupling), max_steps, {"array": 0, "vector": 1}[obs_mode]
+    c.max_current, c.max_duration, c.success_threshold = max_current, max_duration, success_threshold
+    c.energy_penalty_weight, c.temperature = energy_penalty_weight, temperature
+    return c
+
+
+def array_coupling(rows, cols, coupling_type="dipolar", strength=0.1):
+    out = np.zeros((rows * cols, rows * cols))
+    lib().stgo_array_coupling(rows, cols, COUPLING_TYPES[coupling_type], float(strength), _dp(out))
+    return out
+
+
+class ArrayEnvState:
+    """Mutable state of one SpinTorqueArray-v0 env for the oracle."""
+
+    def __init__(self, pattern, target):
+        self.pattern = np.ascontiguousarray(np.asarray(pattern, dtype=np.float64).reshape(-1, 3))
+        self.target = np.ascontiguousarray(np.asarray(target, dtype=np.float64).reshape(-1, 3))
+        self.total_energy = C.c_double(0.0)
+        self.step_count = C.c_int32(0)
+
+
+def array_step(state, action, p, c, coupling):
+    a = np.ascontiguousarray(action, dtype=np.float32)
+    n = c.rows * c.cols
+    obs = np.zeros(n * 6 + (4 if c.obs_mode == 1 else 0), dtype=np.float32)
+    rew, en = C.c_double(), C.c_double()
+    te, tr = C.c_uint8(), C.c_uint8()
+    coupling = np.ascontiguousarray(coupling, dtype=np.float64)
+    lib().stgo_array_step(C.byref(c), C.byref(p), _dp(coupling), _dp(state.pattern), _dp(state.target),
+                          C.byref(state.total_energy), C.byref(state.step_count), a.ctypes.data_as(C.POINTER(C.c_float)),
+                          len(a), obs.ctypes.data_as(C.POINTER(C.c_float)), C.byref(rew), C.byref(te), C.byref(tr),
+                          C.byref(en))
+    return obs, rew.value, bool(te.value), bool(tr.value), en.value
+
+
+def array_observation(state, c):
+    n = c.rows * c.cols
+    obs = np.zeros(n * 6 + (4 if c.obs_mode == 1 else 0), dtype=np.float32)
+    lib().stgo_array_observation(C.byref(c), _dp(state.pattern), _dp(state.target), state.total_energy.value,
+                                 state.step_count.value, obs.ctypes.data_as(C.POINTER(C.c_float)))
+    return obs
+
+
+def device_field(m, p):
+    m = np.ascontiguousarray(m, dtype=np.float64)
+    h = np.zeros(3)
+    lib().stgo_device_field(_dp(m), C.byref(p), _dp(h))
+    return h
 
 
 def env_step(state, action, p, c, env_id=0):

@@ -638,6 +638,161 @@ void stgo_env_step_batch(int64_t n, stgo_env_state* s, const float* actions, con
     }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * SpinTorqueArray-v0
+ * ------------------------------------------------------------------------------------------------ */
+void stgo_array_coupling(int rows, int cols, int type, double strength, double* out) {
+    const int n = rows * cols;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            double v = 0.0;
+            if (i != j) {
+                /* array_env.py:311-332 */
+                int ir = i / cols, ic = i % cols, jr = j / cols, jc = j % cols;
+                double dist = sqrt((double)((ir - jr) * (ir - jr) + (ic - jc) * (ic - jc)));
+                if (type == 0 && dist > 0) v = strength / (dist * dist * dist);
+                else if (type == 1 && dist == 1) v = strength;
+                else if (type == 2 && dist > 0) v = strength / (dist * dist);
+            }
+            out[i * n + j] = v;
+        }
+}
+
+void stgo_device_field(const double m_in[3], const stgo_params* p, double h[3]) {
+    const double hk = 2 * p->ku / (MU0 * p->ms);
+    if (p->dev_type == 0) {
+        /* stt_mram.py:55-76: m re-normalised, raw easy axis, anisotropy only */
+        double mn = norm3(m_in);
+        double m[3] = {m_in[0] / mn, m_in[1] / mn, m_in[2] / mn};
+        double c = hk * dot3(m, p->easy_axis);
+        for (int i = 0; i < 3; ++i) h[i] = 0.0 + c * p->easy_axis[i];
+        return;
+    }
+    /* sot_mram.py:79-112 / vcma_mram.py:85-120: applied(0) + h_anis + h_exchange(0) + h_demag + h_thermal(0) (+ h_dmi(0));
+     * K_eff(0 V) = K for VCMA */
+    double c = hk * dot3(m_in, p->easy_axis);
+    for (int i = 0; i < 3; ++i) {
+        double v = 0.0 + c * p->easy_axis[i];
+        v = v + 0.0;
+        v = v + (-p->ms * p->shape_demag[i]) * m_in[i];
+        h[i] = v + 0.0;
+    }
+}
+
+/* numpy's pairwise summation for n < 128 (np.mean / np.std over the device list): 8 interleaved accumulators */
+static double np_sum(const double* a, int n) {
+    if (n < 8) { double s = 0.0; for (int i = 0; i < n; ++i) s += a[i]; return s; }
+    double r[8];
+    for (int k = 0; k < 8; ++k) r[k] = a[k];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+static double array_similarity(const stgo_array_config* c, const double* pattern, const double* target) {
+    const int n = c->rows * c->cols;
+    double d[256];
+    for (int i = 0; i < n; ++i) d[i] = dot3(&pattern[3 * i], &target[3 * i]);       /* array_env.py:523-531 */
+    return np_sum(d, n) / n;
+}
+
+void stgo_array_observation(const stgo_array_config* c, const double* pattern, const double* target, double total_energy,
+                            int32_t step_count, float* obs) {
+    const int n = c->rows * c->cols;
+    if (c->obs_mode == 0) {                                  /* array_env.py:535-541: [R,C,6] */
+        for (int i = 0; i < n; ++i)
+            for (int k = 0; k < 3; ++k) { obs[6 * i + k] = (float)pattern[3 * i + k]; obs[6 * i + 3 + k] = (float)target[3 * i + k]; }
+        return;
+    }
+    for (int i = 0; i < 3 * n; ++i) { obs[i] = (float)pattern[i]; obs[3 * n + i] = (float)target[i]; }   /* :543-557 */
+    obs[6 * n + 0] = (float)array_similarity(c, pattern, target);
+    obs[6 * n + 1] = (float)((double)(c->max_steps - step_count) / (double)c->max_steps);
+    obs[6 * n + 2] = (float)(total_energy / 1e-12);
+    obs[6 * n + 3] = (float)(c->temperature / 300.0);
+}
+
+void stgo_array_step(const stgo_array_config* c, const stgo_params* p, const double* coupling, double* pattern,
+                     const double* target, double* total_energy, int32_t* step_count, const float* action, int n_action,
+                     float* obs, double* reward, uint8_t* terminated, uint8_t* truncated, double* energy_out) {
+    const int n = c->rows * c->cols;
+    const double prev_sim = array_similarity(c, pattern, target);                     /* array_env.py:372-373 */
+    /* _apply_action (array_env.py:411-476).  Note: in 'global' mode the action is [current, duration], so action[1]
+     * (the duration) is what the reference reads as the current density and the duration defaults to 1 ns. */
+    double J = n_action > 1 ? (double)action[1] : 0.0;
+    double T = n_action > 2 ? (double)action[2] : 1e-9;
+    J = fmin(fmax(J, -c->max_current), c->max_current);
+    T = fmin(fmax(T, 1e-12), c->max_duration);
+    int first = 0, count = 0, stride = 1;
+    if (c->action_mode == 3) { first = 0; count = n; stride = 1; }
+    else {
+        double lim = c->action_mode == 0 ? n - 1 : (c->action_mode == 1 ? c->rows - 1 : c->cols - 1);
+        int idx = (int)fmin(fmax((double)action[0], 0.0), lim);                      /* int(np.clip(action[0], 0, lim)) */
+        if (c->action_mode == 0) { first = idx; count = 1; stride = 1; }
+        else if (c->action_mode == 1) { first = idx * c->cols; count = c->cols; stride = 1; }
+        else { first = idx; count = c->rows; stride = c->cols; }
+    }
+    double e_total = 0.0;
+    for (int q = 0; q < count; ++q) {
+        const int d = first + q * stride;
+        double* m0 = &pattern[3 * d];
+        /* _compute_effective_field (array_env.py:478-494): intrinsic + coupling with the pattern as updated so far */
+        double h[3], hc[3] = {0, 0, 0};
+        stgo_device_field(m0, p, h);
+        if (c->include_coupling)
+            for (int j = 0; j < n; ++j)
+                if (j != d) for (int k = 0; k < 3; ++k) hc[k] += coupling[d * n + j] * pattern[3 * j + k];
+        for (int k = 0; k < 3; ++k) h[k] = h[k] + hc[k];
+        /* _simulate_device_dynamics (array_env.py:496-521): one derivative at m0, ten normalised Euler sub-steps */
+        if (fabs(J) > 1e-12) {
+            const double z[3] = {0, 0, 1};
+            double mxp[3], tau[3], mxh[3], dm[3], mxdm[3];
+            cross3(m0, z, mxp);
+            cross3(m0, mxp, tau);
+            for (int k = 0; k < 3; ++k) tau[k] = 0.1 * J * tau[k];
+            cross3(m0, h, mxh);
+            for (int k = 0; k < 3; ++k) dm[k] = -2.21e5 * mxh[k];
+            cross3(m0, dm, mxdm);
+            for (int k = 0; k < 3; ++k) dm[k] += 0.01 * mxdm[k];
+            for (int k = 0; k < 3; ++k) dm[k] += tau[k];
+            const double dt = T / 10;
+            double m[3] = {m0[0], m0[1], m0[2]};
+            for (int it = 0; it < 10; ++it) {
+                for (int k = 0; k < 3; ++k) m[k] += dm[k] * dt;
+                double nn = norm3(m);
+                for (int k = 0; k < 3; ++k) m[k] = m[k] / nn;
+            }
+            m0[0] = m[0]; m0[1] = m[1]; m0[2] = m[2];
+            /* energy with the resistance of the UPDATED state (current_m is a view of the pattern, :455-463) */
+            double r = stgo_resistance(m0, p);
+            double v = J * r * p->area;
+            e_total += (v * v) / r * T;
+        }
+    }
+    *total_energy += e_total;
+    *step_count += 1;
+    const double sim = array_similarity(c, pattern, target);
+    const int is_success = sim >= c->success_threshold;
+    stgo_array_observation(c, pattern, target, *total_energy, *step_count, obs);
+    /* default reward (array_env.py:183-224) through CompositeReward */
+    double mag[256];
+    for (int i = 0; i < n; ++i) mag[i] = norm3(&pattern[3 * i]);
+    double mean = np_sum(mag, n) / n, dev2[256];
+    for (int i = 0; i < n; ++i) dev2[i] = (mag[i] - mean) * (mag[i] - mean);
+    double uniformity = 1.0 - sqrt(np_sum(dev2, n) / n);
+    if (uniformity < 0) uniformity = 0;
+    double total = 0.0;
+    total += 10.0 * (is_success ? 10.0 : sim * 5.0);
+    total += (-c->energy_penalty_weight) * (-e_total / 1e-12);
+    total += 1.0 * (sim - prev_sim);
+    total += 2.0 * uniformity;
+    *reward = total;
+    *terminated = (uint8_t)is_success;
+    *truncated = (uint8_t)(*step_count >= c->max_steps);
+    if (energy_out) *energy_out = e_total;
+}
+
 int stgo_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

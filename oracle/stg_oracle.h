@@ -42,6 +42,7 @@ typedef struct {
     double sot_tau_dl, sot_tau_fl;  /* SOT: tau_dl_factor, tau_fl_factor (devices/sot_mram.py:61-72) */
     double sot_sigma[3];            /* SOT: z x current_direction (devices/sot_mram.py:180-186) */
     double vcma_xi, vcma_td, vcma_vbd; /* VCMA: vcma_coefficient, dielectric_thickness, breakdown_voltage */
+    double shape_demag[3];          /* SOT/VCMA compute_effective_field: demag factors from 'aspect_ratio' (devices/sot_mram.py:114-132) */
     int32_t dev_type;               /* 0 stt_mram, 1 sot_mram, 2 vcma_mram */
     int32_t params_valid;           /* result of utils/validation.py:176-234 as 'stt_mram' (host-evaluated) */
 } stgo_params;
@@ -146,6 +147,29 @@ void stgo_env_step_batch(int64_t n, stgo_env_state* s, const float* actions /*[n
 void stgo_thermal_normals(uint64_t seed, uint64_t env_id, uint32_t env_step, uint32_t call_idx, double z[3]);
 void stgo_reset_draw(uint64_t seed, uint64_t env_id, uint32_t rng_step, int n_targets, double z[3], int* target_idx);
 void stgo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+/* ---- SpinTorqueArray-v0: envs/array_env.py:362-520 ---- */
+typedef struct {
+    int32_t rows, cols;
+    int32_t action_mode;            /* 0 individual, 1 row, 2 column, 3 global (array_env.py:427-445) */
+    int32_t include_coupling;
+    int32_t max_steps;
+    int32_t obs_mode;               /* 0 'array' (rows*cols*6), 1 'vector' (rows*cols*6 + 4) */
+    double max_current, max_duration, success_threshold, energy_penalty_weight, temperature;
+} stgo_array_config;
+
+/* coupling matrix of array_env.py:301-334; type 0 dipolar, 1 exchange, 2 stray_field; out [n][n] */
+void stgo_array_coupling(int rows, int cols, int type, double strength, double* out);
+/* device.compute_effective_field(m, 0) for the three device classes (stt_mram.py:55-76, sot_mram.py:79-112,
+ * vcma_mram.py:85-120) */
+void stgo_device_field(const double m[3], const stgo_params* p, double h[3]);
+/* one SpinTorqueArrayEnv.step; pattern/target [n][3] row-major; action has n_action floats; obs has
+ * n*6 (+4) floats; returns nothing, fills reward/terminated/truncated/energy */
+void stgo_array_step(const stgo_array_config* c, const stgo_params* p, const double* coupling, double* pattern,
+                     const double* target, double* total_energy, int32_t* step_count, const float* action, int n_action,
+                     float* obs, double* reward, uint8_t* terminated, uint8_t* truncated, double* energy);
+void stgo_array_observation(const stgo_array_config* c, const double* pattern, const double* target, double total_energy,
+                            int32_t step_count, float* obs);
 
 int stgo_max_threads(void);
 

@@ -553,6 +553,7 @@ static int check_cfg(const stg_config* c) {
 
 extern "C" {
 
+int stg_internal_fail(int code, const char* msg) { return fail(code, msg ? msg : ""); }   // used by stg_array.hip
 const char* stg_last_error(void) { return g_err.c_str(); }
 int stg_abi_version(void) { return STG_ABI_VERSION; }
 

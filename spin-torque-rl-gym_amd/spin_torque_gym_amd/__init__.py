@@ -11,11 +11,12 @@ this package does not need a GPU, constructing an environment or solver does.
 from .backend import EnvConfig, HipBackend
 from .devices import (BaseSpintronicDevice, DeviceFactory, SOTMRAMDevice, STTMRAMDevice, VCMAMRAMDevice,
                       flatten_params, params_valid_as_stt)
+from .array_env import SpinTorqueArrayEnv, SpinTorqueArrayVecEnv
 from .envs import SpinTorqueEnv, SpinTorqueVecEnv, register_envs
 
 __version__ = "0.1.0"
 __all__ = ["EnvConfig", "HipBackend", "BaseSpintronicDevice", "DeviceFactory", "STTMRAMDevice", "SOTMRAMDevice",
            "VCMAMRAMDevice", "flatten_params", "params_valid_as_stt", "SpinTorqueEnv", "SpinTorqueVecEnv",
-           "register_envs"]
+           "register_envs", "SpinTorqueArrayEnv", "SpinTorqueArrayVecEnv"]
 
 register_envs()

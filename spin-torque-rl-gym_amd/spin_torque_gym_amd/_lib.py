@@ -35,8 +35,15 @@ class StgDeviceParams(C.Structure):
         ("a_ex", C.c_double), ("area", C.c_double), ("r_p", C.c_double), ("r_ap", C.c_double),
         ("ref_m", C.c_double * 3), ("r_series", C.c_double), ("sot_tau_dl", C.c_double), ("sot_tau_fl", C.c_double),
         ("sot_sigma", C.c_double * 3), ("vcma_xi", C.c_double), ("vcma_td", C.c_double), ("vcma_vbd", C.c_double),
-        ("dev_type", C.c_int32), ("params_valid", C.c_int32),
+        ("shape_demag", C.c_double * 3), ("dev_type", C.c_int32), ("params_valid", C.c_int32),
     ]
+
+
+class StgArrayConfig(C.Structure):
+    _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("action_mode", C.c_int32), ("include_coupling", C.c_int32),
+                ("max_steps", C.c_int32), ("obs_mode", C.c_int32), ("max_current", C.c_double),
+                ("max_duration", C.c_double), ("success_threshold", C.c_double), ("energy_penalty_weight", C.c_double),
+                ("temperature", C.c_double)]
 
 
 # every symbol include/spintorque_hip.h declares: (restype, argtypes)
@@ -58,6 +65,12 @@ SYMBOLS = {
     "stg_solve_traj": (C.c_int, [_VP, _VP, _VP, _VP, C.c_uint32, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "stg_thermal_strength": (C.c_int, [_VP, C.c_int32, C.POINTER(C.c_double)]),
     "stg_thermal_normals": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_int32, _VP, _VP]),
+    "stg_array_create": (C.c_int, [C.POINTER(_VP), C.c_int, C.c_int64, C.c_int64, C.POINTER(StgArrayConfig),
+                                   C.POINTER(StgDeviceParams), C.POINTER(C.c_double)]),
+    "stg_array_destroy": (None, [_VP]),
+    "stg_array_reset": (C.c_int, [_VP, _VP, _VP, _VP, C.c_uint64, _VP, _VP]),
+    "stg_array_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "stg_array_get_state": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
 }
 
 _lib = None

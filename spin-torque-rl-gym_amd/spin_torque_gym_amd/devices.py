@@ -105,6 +105,14 @@ class STTMRAMDevice(BaseSpintronicDevice):
         if not 0 <= p["polarization"] <= 1:
             raise ValueError("Polarization must be between 0 and 1")
 
+    def compute_effective_field(self, magnetization, applied_field):
+        """stt_mram.py:55-76: applied field + uniaxial anisotropy of the re-normalised magnetisation."""
+        m = self.validate_magnetization(magnetization)
+        e = self.get_parameter("easy_axis", np.array([0, 0, 1]))
+        k_u = self.get_parameter("uniaxial_anisotropy", 1e6)
+        ms = self.get_parameter("saturation_magnetization", 800e3)
+        return np.asarray(applied_field, dtype=float) + (2 * k_u / (self.mu0 * ms)) * np.dot(m, e) * e
+
     def compute_resistance(self, magnetization) -> float:
         """stt_mram.py:78-94: R_P (1 + TMR (1 - cos)/2), floor R_P/2; the input is re-normalised."""
         m = self.validate_magnetization(magnetization)
@@ -151,6 +159,13 @@ class SOTMRAMDevice(BaseSpintronicDevice):
         r_mtj = r_p + (r_ap - r_p) * (1 - np.dot(magnetization, self._reference_layer())) / 2
         return max(r_mtj + self.series_resistance(), 1.0)
 
+    def demag_factors(self):
+        return _shape_demag(self.device_params.get("aspect_ratio", 1.0))
+
+    def compute_effective_field(self, magnetization, applied_field):
+        """sot_mram.py:79-112 with zero temperature/DMI: applied + anisotropy + shape demagnetisation."""
+        return _thin_film_field(self, magnetization, applied_field)
+
     def compute_spin_torque(self, current_density, magnetization, current_direction=None):
         """sot_mram.py:163-194: tau_DL = f_dl J (sigma x m), tau_FL = f_fl J sigma, sigma = z x j_hat."""
         j_hat = np.array([1.0, 0.0, 0.0]) if current_direction is None else np.asarray(current_direction, dtype=float)
@@ -187,12 +202,36 @@ class VCMAMRAMDevice(BaseSpintronicDevice):
 
     _compute_effective_anisotropy = effective_anisotropy
 
+    def demag_factors(self):
+        return _shape_demag(self.device_params.get("aspect_ratio", 1.0))
+
+    def compute_effective_field(self, magnetization, applied_field, applied_voltage: float = 0.0):
+        """vcma_mram.py:85-120 with zero temperature: applied + K_eff(V) anisotropy + shape demagnetisation."""
+        return _thin_film_field(self, magnetization, applied_field, self.effective_anisotropy(applied_voltage))
+
     def compute_resistance(self, magnetization) -> float:
         """vcma_mram.py:236-257: R_P + (R_AP - R_P)(1 - cos)/2, floor 1; no re-normalisation."""
         r_p = self.device_params.get("resistance_parallel", 1e3)
         r_ap = self.device_params.get("resistance_antiparallel", 2e3)
         r = r_p + (r_ap - r_p) * (1 - np.dot(magnetization, self._reference_layer())) / 2
         return max(r, 1.0)
+
+
+def _shape_demag(aspect_ratio: float):
+    """sot_mram.py:114-132 / vcma_mram.py:149-166: demagnetisation factors of an elliptical thin film."""
+    if aspect_ratio >= 1.0:
+        n_x, n_y = 1.0 / (1.0 + aspect_ratio), aspect_ratio / (1.0 + aspect_ratio)
+    else:
+        n_x, n_y = aspect_ratio / (1.0 + aspect_ratio), 1.0 / (1.0 + aspect_ratio)
+    return np.array([n_x, n_y, 1.0 - n_x - n_y])
+
+
+def _thin_film_field(device, magnetization, applied_field, k_u=None):
+    e = device.device_params["easy_axis"]
+    k_u = device.device_params["uniaxial_anisotropy"] if k_u is None else k_u
+    ms = device.saturation_magnetization
+    h_anis = (2 * k_u / (device.mu0 * ms)) * np.dot(magnetization, e) * e
+    return applied_field + h_anis + (-ms * device.demag_factors() * magnetization)
 
 
 _DEFAULTS = {
@@ -319,6 +358,9 @@ def flatten_params(device: BaseSpintronicDevice) -> "_lib.StgDeviceParams":
         p.sot_sigma[:] = [float(x) for x in np.cross(np.array([0.0, 0.0, 1.0]), j_hat)]      # sot_mram.py:183-186
     if isinstance(device, VCMAMRAMDevice):
         p.vcma_xi, p.vcma_td, p.vcma_vbd = device.vcma_coefficient, device.dielectric_thickness, device.breakdown_voltage
+    p.shape_demag[:] = [0.0, 0.0, 0.0]
+    if isinstance(device, (SOTMRAMDevice, VCMAMRAMDevice)):
+        p.shape_demag[:] = [float(x) for x in device.demag_factors()]
     if device.device_type not in _lib.DEV_TYPES:
         raise ValueError(f"device type '{device.device_type}' is not supported on the GPU step path")
     p.dev_type = _lib.DEV_TYPES[device.device_type]

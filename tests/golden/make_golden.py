@@ -450,7 +450,61 @@ def G12():
     save("G12_device_terms", **out)
 
 
-ALL = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11, G12=G12)
+def G13():
+    """array_env: SpinTorqueArray-v0 episodes (envs/array_env.py) for the four action modes, three coupling types,
+    both observation modes, STT and SOT/VCMA devices; plus device.compute_effective_field samples."""
+    from spin_torque_gym.envs.array_env import SpinTorqueArrayEnv
+    rng = np.random.default_rng(1313)
+    fac = DeviceFactory()
+    out = {}
+    tags = []
+
+    def add(tag, kwargs, actions, seed):
+        env = SpinTorqueArrayEnv(**kwargs)
+        obs0, _ = env.reset(seed=seed)
+        k = len(tags)
+        rec = dict(obs=[obs0.reshape(-1)], reward=[], terminated=[], truncated=[], energy=[], similarity=[],
+                   pattern=[env.current_pattern.copy()])
+        for a in actions:
+            o, r, te, tr, info = env.step(np.array(a, dtype=np.float32))
+            rec["obs"].append(np.asarray(o).reshape(-1)); rec["reward"].append(r); rec["terminated"].append(te)
+            rec["truncated"].append(tr); rec["energy"].append(info["energy_consumed"])
+            rec["similarity"].append(info["pattern_similarity"]); rec["pattern"].append(env.current_pattern.copy())
+        for name, arr in rec.items():
+            out[f"ep{k}_{name}"] = np.array(arr)
+        out[f"ep{k}_actions"] = np.array(actions, dtype=np.float32)
+        out[f"ep{k}_target"] = env.target_pattern.copy()
+        if getattr(env, "include_coupling", False):
+            out[f"ep{k}_coupling"] = env.coupling_matrix.copy()
+        tags.append(tag)
+        print(f"    G13 episode {k} ({tag}): {len(actions)} steps, final similarity {rec['similarity'][-1]:.4f}")
+
+    def acts(n, idx_hi, jmax=2e6):
+        return [(rng.uniform(-0.5, idx_hi + 0.5), rng.uniform(-jmax, jmax), rng.uniform(1e-10, 2e-9)) for _ in range(n)]
+
+    add("individual_dipolar", dict(array_size=(4, 4), action_mode="individual"), acts(8, 15) + [(3.0, 0.0, 1e-9)], 0)
+    add("row_exchange", dict(array_size=(4, 4), action_mode="row", coupling_type="exchange", coupling_strength=0.3), acts(5, 3), 1)
+    add("column_stray", dict(array_size=(3, 5), action_mode="column", coupling_type="stray_field", observation_mode="vector",
+                             max_steps=4), acts(5, 4), 2)
+    add("global", dict(array_size=(4, 4), action_mode="global"), [(rng.uniform(-2e6, 2e6), rng.uniform(1e-10, 2e-9)) for _ in range(3)], 3)
+    add("nocoupling_custom", dict(array_size=(2, 3), action_mode="individual", include_coupling=False, max_current=1e6,
+                                  max_duration=1e-9, success_threshold=0.2, energy_penalty_weight=0.3,
+                                  observation_mode="vector", temperature=350.0), acts(6, 5, 3e6), 4)
+    sot = fac.get_default_parameters("sot_mram"); sot.update(aspect_ratio=2.0)
+    add("sot_devices", dict(array_size=(3, 3), action_mode="row", device_type="sot_mram", device_params=sot), acts(4, 2, 1e3), 5)
+    vc = fac.get_default_parameters("vcma_mram"); vc.update(aspect_ratio=0.5, reference_magnetization=np.array([0.0, 0.2, 1.0]))
+    add("vcma_devices", dict(array_size=(2, 2), action_mode="individual", device_type="vcma_mram", device_params=vc), acts(4, 3, 1e3), 6)
+    out["episode_tags"] = np.array(tags)
+    # device.compute_effective_field(m, 0) samples
+    ms_ = unit_rows(rng, 12) * rng.uniform(0.5, 1.5, (12, 1))
+    out["field_m"] = ms_
+    for t, params in (("stt_mram", fac.get_default_parameters("stt_mram")), ("sot_mram", sot), ("vcma_mram", vc)):
+        dev = fac.create_device(t, params)
+        out[f"field_{t}"] = np.array([dev.compute_effective_field(m.copy(), np.zeros(3)) for m in ms_])
+    save("G13_array_env", **out)
+
+
+ALL = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11, G12=G12, G13=G13)
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

@@ -257,3 +257,55 @@ def make_states(n, m, target):
 def unit_rows(rng, n):
     v = rng.normal(0, 1, (n, 3))
     return v / np.linalg.norm(v, axis=1, keepdims=True)
+
+
+class OracleArrayBackend:
+    """HipArrayBackend's interface on the CPU oracle (test seam of SpinTorqueArrayVecEnv)."""
+
+    def __init__(self, n_arrays, cfg, dev_params, coupling, device_index=0, env_id0=0):
+        self.n, self.cfg = int(n_arrays), cfg
+        self.n_dev = cfg.rows * cfg.cols
+        self.obs_dim = self.n_dev * 6 + (4 if cfg.obs_mode == 1 else 0)
+        self.device = torch.device("cpu")
+        self.ocfg = oracle.ArrayConfig()
+        C.memmove(C.byref(self.ocfg), C.byref(cfg), C.sizeof(oracle.ArrayConfig))
+        self.p = oracle_params([dev_params])[0]
+        self.coupling = np.zeros((self.n_dev, self.n_dev)) if coupling is None else np.ascontiguousarray(coupling, dtype=np.float64)
+        self.states = [None] * self.n
+        self.target = None
+        n = self.n
+        self.obs = torch.zeros((self.obs_dim, n), dtype=torch.float32)
+        self.reward = torch.zeros(n, dtype=torch.float32)
+        self.reward64 = torch.zeros(n, dtype=torch.float64)
+        self.energy = torch.zeros(n, dtype=torch.float64)
+        self.terminated = torch.zeros(n, dtype=torch.uint8)
+        self.truncated = torch.zeros(n, dtype=torch.uint8)
+
+    def close(self):
+        pass
+
+    def reset(self, mask=None, init_pattern=None, target=None, seed=0):
+        assert init_pattern is not None, "the oracle backend takes explicit initial patterns"
+        ip = torch.as_tensor(init_pattern).numpy()
+        for i in range(self.n):
+            if mask is not None and not bool(mask[i]):
+                continue
+            tg = torch.as_tensor(target).numpy()[:, i].reshape(-1, 3) if target is not None else self.states[i].target
+            self.states[i] = oracle.ArrayEnvState(ip[:, i].reshape(-1, 3), tg)
+            self.obs[:, i] = torch.from_numpy(oracle.array_observation(self.states[i], self.ocfg))
+        return self.obs
+
+    def step(self, actions):
+        a = torch.as_tensor(actions).numpy().astype(np.float32)
+        for i in range(self.n):
+            obs, r, te, tr, en = oracle.array_step(self.states[i], a[:, i], self.p, self.ocfg, self.coupling)
+            self.obs[:, i] = torch.from_numpy(obs)
+            self.reward[i] = float(np.float32(r)); self.reward64[i] = r; self.energy[i] = en
+            self.terminated[i] = int(te); self.truncated[i] = int(tr)
+        return self.obs, self.reward, self.reward64, self.terminated, self.truncated
+
+    def get_state(self):
+        return dict(pattern=torch.from_numpy(np.stack([s.pattern.reshape(-1) for s in self.states], axis=1).copy()),
+                    target=torch.from_numpy(np.stack([s.target.reshape(-1) for s in self.states], axis=1).copy()),
+                    total_energy=torch.tensor([s.total_energy.value for s in self.states], dtype=torch.float64),
+                    step_count=torch.tensor([s.step_count.value for s in self.states], dtype=torch.int32))

@@ -670,3 +670,99 @@ def test_device_torque_model_mixed_batch_vs_oracle(stg, thermal):
     dm = np.abs(outs[0][1]["m"] - ref_mode[0][1]["m"]).max(axis=0)
     assert np.all(dm[cls == 0] == 0.0)                       # STT lanes: identical bits in both models
     assert dm[cls == 1].max() > 1e-6 and dm[cls == 2].max() > 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# SpinTorqueArray-v0
+# ------------------------------------------------------------------------------------------------
+def _array_kwargs(tag):
+    from test_oracle_golden import G13_EPISODES, array_device_params
+    ckw, coup, dev, over = G13_EPISODES[tag]
+    kw = dict(array_size=(ckw["rows"], ckw["cols"]), action_mode=ckw["action_mode"], device_type=dev,
+              device_params=array_device_params(dev, over) if (over or dev != "stt_mram") else None,
+              observation_mode=ckw.get("obs_mode", "array"), include_coupling=ckw.get("include_coupling", True))
+    for key in ("max_steps", "max_current", "max_duration", "success_threshold", "energy_penalty_weight", "temperature"):
+        if key in ckw:
+            kw[key] = ckw[key]
+    if coup:
+        kw.update(coupling_type=coup[0], coupling_strength=coup[1])
+    return kw
+
+
+def test_array_env_vs_golden_g13(stg, golden):
+    """SpinTorqueArrayEnv on the HIP path against recorded reference episodes (all action modes, coupling types,
+    observation modes, STT/SOT/VCMA cells)."""
+    g = golden("G13_array_env")
+    worst = 0.0
+    for k, tag in enumerate(g["episode_tags"]):
+        tag = str(tag)
+        env = stg.SpinTorqueArrayEnv(**_array_kwargs(tag))
+        obs, _ = env.reset(seed=k)
+        assert np.abs(env.current_pattern - g[f"ep{k}_pattern"][0]).max() <= 1e-15, tag
+        assert np.allclose(obs.reshape(-1), g[f"ep{k}_obs"][0], rtol=2e-7, atol=1e-12), tag
+        for j, a in enumerate(g[f"ep{k}_actions"]):
+            obs, r, te, tr, info = env.step(a)
+            worst = max(worst, np.abs(env.current_pattern - g[f"ep{k}_pattern"][j + 1]).max())
+            assert np.abs(env.current_pattern - g[f"ep{k}_pattern"][j + 1]).max() <= 1e-11, (tag, j)
+            assert np.allclose(obs.reshape(-1), g[f"ep{k}_obs"][j + 1], rtol=3e-7, atol=1e-10), (tag, j)
+            rr = g[f"ep{k}_reward"][j]
+            assert abs(r - rr) <= 1e-9 * max(1.0, abs(rr)), (tag, j, r, rr)
+            assert te == bool(g[f"ep{k}_terminated"][j]) and tr == bool(g[f"ep{k}_truncated"][j]), (tag, j)
+            ee = g[f"ep{k}_energy"][j]
+            assert abs(info["energy_consumed"] - ee) <= 1e-10 * max(abs(ee), 1e-300), (tag, j)
+        env.close()
+    print("array env worst |dm| vs reference =", worst)
+
+
+@pytest.mark.parametrize("mode", ["individual", "row", "column", "global"])
+def test_array_vec_env_vs_oracle(stg, mode):
+    from helpers import OracleArrayBackend
+    n, size = 640, (4, 4)
+    rng = np.random.default_rng(9)
+    v = rng.normal(0, 1, (n, 4, 4, 3))
+    init = v / np.linalg.norm(v, axis=-1, keepdims=True)
+    hi = {"individual": 15, "row": 3, "column": 3}
+    res = []
+    for backend in (None, OracleArrayBackend):
+        env = stg.SpinTorqueArrayVecEnv(n, size, action_mode=mode, coupling_type="dipolar", coupling_strength=0.2,
+                                        success_threshold=0.05, max_steps=3, backend=backend)
+        obs, _ = env.reset(options={"initial_pattern": init})
+        rec = [obs.cpu().numpy().copy()]
+        arng = np.random.default_rng(10)
+        for s in range(4):
+            if mode == "global":
+                a = np.stack([arng.uniform(-2e6, 2e6, n), arng.uniform(1e-13, 1e-10, n)], axis=1).astype(np.float32)
+            else:
+                a = np.stack([arng.uniform(-1, hi[mode] + 1, n), arng.uniform(-3e6, 3e6, n), arng.uniform(-1e-10, 6e-9, n)],
+                             axis=1).astype(np.float32)
+                a[::9, 1] = 0.0
+            obs, r, te, tr, info = env.step(torch.from_numpy(a))
+            rec.append((obs.cpu().numpy().copy(), info["reward_f64"].cpu().numpy().copy(), te.cpu().numpy().copy(),
+                        tr.cpu().numpy().copy(), info["energy"].cpu().numpy().copy(),
+                        env.get_state()["pattern"].cpu().numpy().copy()))
+        res.append(rec)
+        env.close()
+    hip, ora = res
+    assert np.allclose(hip[0], ora[0], rtol=2e-7, atol=1e-12)
+    for s in range(1, 5):
+        assert np.abs(hip[s][5] - ora[s][5]).max() <= 1e-11, (mode, s)
+        assert np.allclose(hip[s][0], ora[s][0], rtol=3e-7, atol=1e-10) and np.allclose(hip[s][1], ora[s][1], rtol=1e-9, atol=1e-9)
+        assert np.array_equal(hip[s][2], ora[s][2]) and np.array_equal(hip[s][3], ora[s][3])
+        assert np.allclose(hip[s][4], ora[s][4], rtol=1e-10, atol=0)
+    assert hip[3][3].all() and hip[1][2].any()          # truncation at max_steps, some early successes
+
+
+def test_array_env_sizes_and_device_reset(stg):
+    """8 x 8 cells (LDS: 98 KB pattern + 32 KB coupling per wavefront), device-side random reset, ragged batch."""
+    n = 1000
+    env = stg.SpinTorqueArrayVecEnv(n, (8, 8), action_mode="global", seed=4)
+    obs, _ = env.reset(seed=2)
+    st = env.get_state()
+    pat = st["pattern"].reshape(64, 3, n)
+    assert torch.all(torch.abs(torch.linalg.norm(pat, dim=1) - 1) < 1e-12)
+    tgt = st["target"].reshape(64, 3, n)[:, 2, 0].reshape(8, 8).cpu().numpy()
+    assert np.array_equal(tgt, np.where((np.add.outer(np.arange(8), np.arange(8)) % 2) == 0, 1.0, -1.0))
+    a = torch.zeros((n, 2)); a[:, 1] = 1.0
+    obs, r, te, tr, info = env.step(a)
+    assert tuple(obs.shape) == (n, 64 * 6) and torch.isfinite(obs).all() and torch.isfinite(r).all()
+    env.close()

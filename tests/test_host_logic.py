@@ -186,3 +186,44 @@ def test_solver_facades_vs_golden(stg, golden):
     white = np.array([tf.generate_thermal_field(0.01, 800e3, params["volume"], 1e-12, correlated=False) for _ in range(4000)])
     assert np.allclose(white.std(axis=0), g8["tf_white_std"], rtol=1e-12)      # same seeded generator as the reference
     assert ThermalFluctuations(0.0).compute_noise_strength(0.01, 8e5, 1e-24) == 0.0
+
+
+def test_array_env_facade_vs_golden_g13(stg, golden):
+    """SpinTorqueArrayEnv facade (host code) over the oracle backend: reset draws (PCG64), step outputs, info keys."""
+    from helpers import OracleArrayBackend
+    from test_oracle_golden import G13_EPISODES, array_device_params
+    g = golden("G13_array_env")
+    seeds = dict(zip([str(t) for t in g["episode_tags"]], range(len(g["episode_tags"]))))
+    for k, tag in enumerate(g["episode_tags"]):
+        tag = str(tag)
+        ckw, coup, dev, over = G13_EPISODES[tag]
+        kw = dict(array_size=(ckw["rows"], ckw["cols"]), action_mode=ckw["action_mode"], device_type=dev,
+                  device_params=array_device_params(dev, over) if (over or dev != "stt_mram") else None,
+                  observation_mode=ckw.get("obs_mode", "array"), include_coupling=ckw.get("include_coupling", True))
+        for key in ("max_steps", "max_current", "max_duration", "success_threshold", "energy_penalty_weight", "temperature"):
+            if key in ckw:
+                kw[key] = ckw[key]
+        if coup:
+            kw.update(coupling_type=coup[0], coupling_strength=coup[1])
+        env = stg.SpinTorqueArrayEnv(backend=OracleArrayBackend, **kw)
+        obs, info = env.reset(seed=seeds[tag])
+        assert np.abs(env.current_pattern - g[f"ep{k}_pattern"][0]).max() <= 1e-15, tag         # same PCG64 draws
+        assert np.allclose(obs.reshape(-1), g[f"ep{k}_obs"][0], rtol=2e-7, atol=1e-12), tag
+        if coup:
+            assert np.allclose(env.coupling_matrix, g[f"ep{k}_coupling"], rtol=1e-15, atol=0), tag
+        for j, a in enumerate(g[f"ep{k}_actions"]):
+            obs, r, te, tr, info = env.step(a)
+            assert obs.shape == ((ckw["rows"], ckw["cols"], 6) if kw["observation_mode"] == "array" else (ckw["rows"] * ckw["cols"] * 6 + 4,))
+            assert np.allclose(obs.reshape(-1), g[f"ep{k}_obs"][j + 1], rtol=2e-7, atol=1e-12), (tag, j)
+            assert abs(r - g[f"ep{k}_reward"][j]) <= 1e-11 * max(1.0, abs(g[f"ep{k}_reward"][j])), (tag, j)
+            assert te == bool(g[f"ep{k}_terminated"][j]) and tr == bool(g[f"ep{k}_truncated"][j])
+            assert abs(info["pattern_similarity"] - g[f"ep{k}_similarity"][j]) <= 1e-12
+            for key in ("energy_consumed", "affected_devices", "current_density", "pulse_duration", "pattern_improvement"):
+                assert key in info
+        env.close()
+    with pytest.raises(ValueError):
+        stg.SpinTorqueArrayEnv(action_mode="bogus", backend=OracleArrayBackend)
+    env = stg.SpinTorqueArrayEnv(backend=OracleArrayBackend)
+    env.reset(seed=0)
+    with pytest.raises(ValueError, match="NaN"):
+        env.step(np.array([np.nan, 1e6, 1e-9], dtype=np.float32))
