@@ -766,3 +766,19 @@ def test_array_env_sizes_and_device_reset(stg):
     obs, r, te, tr, info = env.step(a)
     assert tuple(obs.shape) == (n, 64 * 6) and torch.isfinite(obs).all() and torch.isfinite(r).all()
     env.close()
+
+
+def test_integration_md_ctypes_stub_runs(stg):
+    """The ctypes stub printed in INTEGRATION.md section 3 runs as written (only the library path is substituted)."""
+    import os
+    import re
+    from conftest import ROOT
+    from spin_torque_gym_amd import _lib
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = [b for b in re.findall(r"```python\n(.*?)```", txt, flags=re.S) if "stg_create" in b][0]
+    block = block.replace('C.CDLL("libspintorque_hip.so")', f'C.CDLL({_lib.LIB_PATH!r})')
+    ns = {}
+    exec(block, ns)
+    torch.cuda.synchronize()
+    obs = ns["obs"]
+    assert torch.isfinite(obs).all() and torch.all(torch.abs(torch.linalg.norm(obs[:3].double(), dim=0) - 1) < 1e-6)
