@@ -260,7 +260,7 @@ def cpu_baseline(solver, thermal, seconds):
     c = oracle.make_config(solver=solver, thermal=bool(thermal), seed=1234)
     threads = usable_cores(oracle.lib().stgo_max_threads())
     done_steps, t_used, batches = 0, 0.0, 0
-    while t_used < seconds and batches < 64:
+    while t_used < seconds and batches < 4096:
         st = make_states(n, m0, tgt)
         a = np.empty((n, 2), dtype=np.float32)
         a[:, 0] = rng.uniform(-2e6, 2e6, n)
