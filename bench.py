@@ -56,6 +56,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--lane-sort", default="auto", choices=["auto", "on", "off"],
                     help="duration-sorted lane schedule (auto = on)")
+    ap.add_argument("--wave-spec", default="auto", choices=["auto", "on", "off"],
+                    help="producer/consumer wavefront pairs for the thermal kernels (auto = on up to 131072 envs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank code path on a single GPU)")
     return ap.parse_args()
@@ -82,12 +84,12 @@ def volume_for(solver):
 
 
 def run_config(n_local, solver, thermal, steps, warmup, rank, world, device_index, mixed=False, seed=1234, lane_sort=None,
-               torque_model="reference"):
+               torque_model="reference", wave_spec=None):
     """Builds the env, runs warmup + timed steps, returns a dict of measurements (times are this rank's)."""
     import spin_torque_gym_amd as stg
     import torch.distributed as dist
     kw = dict(include_thermal_fluctuations=bool(thermal), temperature=300.0, solver=solver, seed=seed, autoreset=True,
-              lane_sort=lane_sort, torque_model=torque_model)
+              lane_sort=lane_sort, torque_model=torque_model, wave_spec=wave_spec)
     if mixed:
         fac = stg.DeviceFactory()
         sot = fac.get_default_parameters("sot_mram"); sot.update(polarization=0.7, volume=volume_for(solver))
@@ -296,7 +298,9 @@ def main():
             dist.init_process_group(args.backend)
     n_local = args.envs_per_gpu
     lane_sort = {"auto": None, "on": True, "off": False}[args.lane_sort]
-    meas = run_config(n_local, args.solver, args.thermal, args.steps, args.warmup, rank, world, local_rank, lane_sort=lane_sort)
+    wave_spec = {"auto": None, "on": True, "off": False}[args.wave_spec]
+    meas = run_config(n_local, args.solver, args.thermal, args.steps, args.warmup, rank, world, local_rank, lane_sort=lane_sort,
+                      wave_spec=wave_spec)
     wall = torch.tensor([meas["wall_s"]], dtype=torch.float64, device=torch.device("cuda", local_rank))
     if world > 1:
         dist.all_reduce(wall, op=dist.ReduceOp.MAX)

@@ -100,15 +100,15 @@ __device__ __forceinline__ LlgsEnergyK load_energy(const double* r) {
     return LlgsEnergyK{r[C_KUV], r[C_EDEMAG], V3{r[C_RX], r[C_RY], r[C_RZ]}, V3{r[C_NX], r[C_NY], r[C_NZ]}};
 }
 
-template <int SOLVER, bool THERMAL, bool RECORD, bool AXIS_Z, bool DEVPHYS>
+template <int SOLVER, bool THERMAL, bool RECORD, bool AXIS_Z, bool DEVPHYS, class NSRC>
 __device__ __forceinline__ SolveOut run_solver(const V3& m, double J, double T, const double* row, const CfgView& c,
-                                               const RngKey& rk, const Recorder& rec) {
+                                               const RngKey& rk, const Recorder& rec, NSRC& ns) {
     if (SOLVER == STG_SOLVER_RK45) {
         const LlgsK k = load_llgs(row);
         LlgsEnergyK ek{};
         if (RECORD) ek = load_energy(row);
         return llgs_solve<THERMAL, RECORD, AXIS_Z>(m, J, T, k, row[C_BETA], row[C_BETAP], c.rtol, c.atol, c.max_step,
-                                                   c.max_attempts, rk, rec, ek);
+                                                   c.max_attempts, rk, rec, ek, ns);
     }
     const SimpleK k = load_simple(row);
     DevTorque dv{0.0, 0.0, V3{0.0, 1.0, 0.0}, k.hk, false};
@@ -133,13 +133,14 @@ __device__ __forceinline__ SolveOut run_solver(const V3& m, double J, double T, 
         }
     }
     return simple_solve<SOLVER == STG_SOLVER_EULER ? 1 : 0, THERMAL, RECORD, AXIS_Z, DEVPHYS>(
-        m, J, T, k, pol, row[C_MSV], row[C_VALID] != 0.0, c.temperature, c.max_step, rk, rec, dv);
+        m, J, T, k, pol, row[C_MSV], row[C_VALID] != 0.0, c.temperature, c.max_step, rk, rec, dv, ns);
 }
 
 // SpinTorqueEnv.reset draws (spin_torque_env.py:286-299) from the device generator: normal(0,1,3) normalised and a
 // uniform choice among the target states, from this env's stream tagged 0xFFFFFFFF (the thermal field uses tag 0).
 __device__ __forceinline__ void device_reset_draw(uint64_t seed, uint64_t env_id, uint32_t rng_step, const CfgView& c,
                                                   bool draw_m, bool draw_t, V3& m, V3& tgt) {
+#pragma clang fp contract(off)
     NormalStream ns;
     ns.init(seed ^ 0x9E3779B97F4A7C15ull, env_id, rng_step, 0xFFFFFFFFu);
     const V3 z = ns.draw3_even();
@@ -157,6 +158,7 @@ __device__ __forceinline__ void device_reset_draw(uint64_t seed, uint64_t env_id
 // A12: _get_observation (vector mode), written component-major.
 __device__ __forceinline__ void write_obs(float* obs, int64_t N, int64_t i, const V3& m, const V3& tgt, const double* row,
                                           const CfgView& c, int32_t step, double etot, double J, double T) {
+#pragma clang fp contract(off)
     const V3 ref{row[C_REFX], row[C_REFY], row[C_REFZ]};
     const double r = resistance(m, (int)row[C_DEVTYPE], row[C_RP], row[C_RAP], row[C_TMR], ref, row[C_RSERIES]);
     obs[0 * N + i] = obs_cast(m.x);
@@ -211,18 +213,42 @@ __device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nblocks, 
 // ------------------------------------------------------------------------------------------------
 // env.step kernel (A10-A14 around the solver), K fused steps per launch
 // ------------------------------------------------------------------------------------------------
-template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, bool DEVPHYS, typename AT>
-__global__ void __launch_bounds__(64) stg_step_kernel(const StepArgs a) {
+// PC = producer/consumer wave specialisation (thermal only): 128-thread workgroups whose first wavefront integrates 64
+// envs while the second runs the same envs' normal streams one chunk ahead into LDS (stg_physics.hpp: SharedNormals).
+// Same values in the same order, so results are identical; it pays when the launch is latency-bound (<= ~2 waves/SIMD).
+template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, bool DEVPHYS, typename AT, bool PC>
+__global__ void __launch_bounds__(PC ? 128 : 64) stg_step_kernel(const StepArgs a) {
+    // the env-step arithmetic around the solver (energy, reward, flags) has no contraction: same roundings in every
+    // instantiation, and the same as NumPy's
+#pragma clang fp contract(off)
+    static_assert(!PC || THERMAL, "wave specialisation only exists for the thermal kernels");
     __shared__ double s_tab[MULTI ? STG_MAX_CLASSES * C_COUNT : 1];
-    const int64_t lane_slot = stg_slot_block(blockIdx.x, gridDim.x, a.perm != nullptr) * 64 + threadIdx.x;
+    __shared__ float s_norm[PC ? 2 * SHARED_CHUNK_MAX * 64 : 1];
+    __shared__ int s_alive[2], s_go[2];
+    __shared__ uint32_t s_rng[PC ? 64 : 1];
+    const int lane = PC ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
+    const int64_t lane_slot = stg_slot_block(blockIdx.x, gridDim.x, a.perm != nullptr) * 64 + lane;
     const bool in_range = lane_slot < a.N;
     // duration-sorted schedule: slot j of the launch integrates env perm[j], so the 64 lanes of a wavefront have
     // (nearly) equal trip counts; all state and outputs stay at the env's own index
     const int64_t i = in_range ? (a.perm ? (int64_t)a.perm[lane_slot] : lane_slot) : 0;
     const double* row = class_row<MULTI>(a.ctab, a.cls, a.ncls, i, in_range, s_tab);
-    if (!in_range) return;
+    if (!in_range) return;      // (PC: whole lanes of both wavefronts leave; barriers are per wavefront)
     const int64_t N = a.N;
     const uint64_t env_id = (uint64_t)(a.env_id0 + i);
+
+    if (PC && threadIdx.x >= 64) {
+        // producer wavefront: per env-step, wait for the consumer's stream position, then stay one chunk ahead
+        constexpr int n_first = SOLVER == STG_SOLVER_RK45 ? 6 : (SOLVER == STG_SOLVER_RK4 ? 12 : 3);
+        constexpr int n_chunk = SOLVER == STG_SOLVER_RK45 ? 18 : n_first;
+        for (int k = 0; k < a.K; ++k) {
+            __syncthreads();                                       // H1: s_rng / s_go[k & 1] published
+            if (!s_go[k & 1]) continue;
+            const RngKey rk{a.c.seed, env_id, s_rng[lane]};
+            produce_normals(s_norm, s_alive, lane, rk, n_first, n_chunk);
+        }
+        return;
+    }
 
     V3 m{a.s.mx[i], a.s.my[i], a.s.mz[i]};
     V3 tgt{a.s.tx[i], a.s.ty[i], a.s.tz[i]};
@@ -244,6 +270,15 @@ __global__ void __launch_bounds__(64) stg_step_kernel(const StepArgs a) {
         uint8_t st;
         double reward, energy = 0.0;
         bool is_success, truncated;
+        SharedNormals shared{s_norm, s_alive, lane, 0, 0};
+        InlineNormals inl;
+        if (PC) {
+            const bool wave_go = __ballot(!(a.c.skip_done && done)) != 0ull;
+            s_rng[lane] = rng;
+            s_go[k & 1] = wave_go ? 1 : 0;
+            __syncthreads();                                       // H1
+            if (wave_go) __syncthreads();                          // H2: chunk 0 is in LDS
+        }
         if (a.c.skip_done && done) {
             // wavefront-level early-out: a wave whose lanes are all done skips the integrator entirely
             st = STG_STATUS_INACTIVE; reward = 0.0;
@@ -252,7 +287,9 @@ __global__ void __launch_bounds__(64) stg_step_kernel(const StepArgs a) {
         } else {
             const double prev_align = dot(m, tgt);                                   // spin_torque_env.py:338-339
             const RngKey rk{a.c.seed, env_id, rng};
-            const SolveOut so = run_solver<SOLVER, THERMAL, false, AXIS_Z, DEVPHYS>(m, J, T, row, a.c, rk, norec);
+            SolveOut so;
+            if (PC) so = run_solver<SOLVER, THERMAL, false, AXIS_Z, DEVPHYS>(m, J, T, row, a.c, rk, norec, shared);
+            else so = run_solver<SOLVER, THERMAL, false, AXIS_Z, DEVPHYS>(m, J, T, row, a.c, rk, norec, inl);
             if (fabs(J) > 1e-12) {                                                   // spin_torque_env.py:474-480
                 const V3 ref{row[C_REFX], row[C_REFY], row[C_REFZ]};
                 const double r = resistance(m, (int)row[C_DEVTYPE], row[C_RP], row[C_RAP], row[C_TMR], ref, row[C_RSERIES]);
@@ -326,7 +363,8 @@ __global__ void __launch_bounds__(64) stg_solve_kernel(const SolveArgs a) {
     const V3 m0{a.m0[i], a.m0[N + i], a.m0[2 * N + i]};
     const RngKey rk{a.c.seed, (uint64_t)(a.env_id0 + i), a.env_step};
     const Recorder rec{a.traj_t, a.traj_m, a.traj_e, N, i, a.traj_cap};
-    const SolveOut so = run_solver<SOLVER, THERMAL, RECORD, false, false>(m0, a.J[i], a.T[i], row, a.c, rk, rec);
+    InlineNormals ns;
+    const SolveOut so = run_solver<SOLVER, THERMAL, RECORD, false, false>(m0, a.J[i], a.T[i], row, a.c, rk, rec, ns);
     a.m_final[i] = so.m.x; a.m_final[N + i] = so.m.y; a.m_final[2 * N + i] = so.m.z;
     if (a.n_points) a.n_points[i] = so.n;
     if (a.success) a.success[i] = so.ok ? 1 : 0;
@@ -673,6 +711,9 @@ int stg_thermal_strength(stg_ctx* ctx, int32_t cls, double* out) {
     return STG_OK;
 }
 
+// largest launch the automatic wave specialisation applies to: 2 integrating wavefronts per SIMD (256 CUs x 4 SIMDs x 64)
+constexpr int64_t STG_WAVE_SPEC_MAX_ENVS = 2 * 65536;
+
 static inline dim3 grid_for(int64_t N) { return dim3((unsigned)((N + 63) / 64)); }
 
 int stg_reset(stg_ctx* ctx, const uint8_t* mask, const double* init_m, const double* target, uint64_t seed,
@@ -692,27 +733,36 @@ int stg_reset(stg_ctx* ctx, const uint8_t* mask, const double* init_m, const dou
 
 extern "C++" {
 template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, bool DEVPHYS>
-static void launch_step(const StepArgs& a, int act_f64, hipStream_t st) {
+static void launch_step(const StepArgs& a, int act_f64, bool pc, hipStream_t st) {
+    if (THERMAL && !DEVPHYS && pc) {
+        // wave-specialised variant (same grid, 2 wavefronts per workgroup); not built for the device-physics model
+        constexpr bool PC = THERMAL && !DEVPHYS;
+        if (act_f64)
+            hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, double, PC>), grid_for(a.N), dim3(128), 0, st, a);
+        else
+            hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, float, PC>), grid_for(a.N), dim3(128), 0, st, a);
+        return;
+    }
     if (act_f64)
-        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, double>), grid_for(a.N), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, double, false>), grid_for(a.N), dim3(64), 0, st, a);
     else
-        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, float>), grid_for(a.N), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, float, false>), grid_for(a.N), dim3(64), 0, st, a);
 }
 template <int SOLVER, bool AXIS_Z, bool DEVPHYS>
-static void dispatch_step2(const StepArgs& a, bool thermal, bool multi, int act_f64, hipStream_t st) {
-    if (thermal) { if (multi) launch_step<SOLVER, true, true, AXIS_Z, DEVPHYS>(a, act_f64, st); else launch_step<SOLVER, true, false, AXIS_Z, DEVPHYS>(a, act_f64, st); }
-    else { if (multi) launch_step<SOLVER, false, true, AXIS_Z, DEVPHYS>(a, act_f64, st); else launch_step<SOLVER, false, false, AXIS_Z, DEVPHYS>(a, act_f64, st); }
+static void dispatch_step2(const StepArgs& a, bool thermal, bool multi, int act_f64, bool pc, hipStream_t st) {
+    if (thermal) { if (multi) launch_step<SOLVER, true, true, AXIS_Z, DEVPHYS>(a, act_f64, pc, st); else launch_step<SOLVER, true, false, AXIS_Z, DEVPHYS>(a, act_f64, pc, st); }
+    else { if (multi) launch_step<SOLVER, false, true, AXIS_Z, DEVPHYS>(a, act_f64, false, st); else launch_step<SOLVER, false, false, AXIS_Z, DEVPHYS>(a, act_f64, false, st); }
 }
 // axis_z selects the easy-axis = z specialisation of the RHS (Simple: e = +z; LLGS: raw axis and demag along z);
 // devphys the opt-in device-physics torque model (fixed-step solvers only)
 template <int SOLVER>
-static void dispatch_step(const StepArgs& a, bool thermal, bool multi, bool axis_z, bool devphys, int act_f64, hipStream_t st) {
+static void dispatch_step(const StepArgs& a, bool thermal, bool multi, bool axis_z, bool devphys, int act_f64, bool pc, hipStream_t st) {
     if (SOLVER != STG_SOLVER_RK45 && devphys) {
-        if (axis_z) dispatch_step2<SOLVER, true, true>(a, thermal, multi, act_f64, st);
-        else dispatch_step2<SOLVER, false, true>(a, thermal, multi, act_f64, st);
+        if (axis_z) dispatch_step2<SOLVER, true, true>(a, thermal, multi, act_f64, pc, st);
+        else dispatch_step2<SOLVER, false, true>(a, thermal, multi, act_f64, pc, st);
     } else {
-        if (axis_z) dispatch_step2<SOLVER, true, false>(a, thermal, multi, act_f64, st);
-        else dispatch_step2<SOLVER, false, false>(a, thermal, multi, act_f64, st);
+        if (axis_z) dispatch_step2<SOLVER, true, false>(a, thermal, multi, act_f64, pc, st);
+        else dispatch_step2<SOLVER, false, false>(a, thermal, multi, act_f64, pc, st);
     }
 }
 }  // extern "C++"
@@ -753,10 +803,13 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
     const bool thermal = ctx->cfg.thermal && ctx->cfg.temperature > 0;
     const bool multi = ctx->ncls > 1;
     const bool devphys = ctx->cfg.torque_model == 1;
+    // wave_spec: 0 = automatic (thermal launches of at most STG_WAVE_SPEC_MAX_ENVS envs, i.e. latency-bound ones),
+    // 1 = always, -1 = never.  Results do not depend on it.
+    const bool pc = ctx->cfg.wave_spec > 0 || (ctx->cfg.wave_spec == 0 && ctx->N <= STG_WAVE_SPEC_MAX_ENVS);
     switch (ctx->cfg.solver) {
-        case STG_SOLVER_RK4: dispatch_step<STG_SOLVER_RK4>(a, thermal, multi, ctx->axis_z, devphys, act_f64, st); break;
-        case STG_SOLVER_EULER: dispatch_step<STG_SOLVER_EULER>(a, thermal, multi, ctx->axis_z, devphys, act_f64, st); break;
-        default: dispatch_step<STG_SOLVER_RK45>(a, ctx->cfg.thermal != 0, multi, ctx->axis_z_llgs, false, act_f64, st); break;
+        case STG_SOLVER_RK4: dispatch_step<STG_SOLVER_RK4>(a, thermal, multi, ctx->axis_z, devphys, act_f64, pc, st); break;
+        case STG_SOLVER_EULER: dispatch_step<STG_SOLVER_EULER>(a, thermal, multi, ctx->axis_z, devphys, act_f64, pc, st); break;
+        default: dispatch_step<STG_SOLVER_RK45>(a, ctx->cfg.thermal != 0, multi, ctx->axis_z_llgs, false, act_f64, pc, st); break;
     }
     HIP_TRY(hipGetLastError());
     return STG_OK;

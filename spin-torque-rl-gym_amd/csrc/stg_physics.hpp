@@ -108,10 +108,16 @@ __device__ __forceinline__ double inv_tenth_root(double e2) {
     return __builtin_fma(y * e, __builtin_fma(0.055, e, 0.1), y);     // y (1 + e/10 + 11 e^2/200)
 }
 
+// cross/dot spell their FMAs out (contraction of a*b - c*d is otherwise the backend's choice and can change with the
+// surrounding code, i.e. between two instantiations of the same source)
 __device__ __forceinline__ V3 cross(const V3& a, const V3& b) {
-    return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+#pragma clang fp contract(off)
+    return V3{__builtin_fma(a.y, b.z, -(a.z * b.y)), __builtin_fma(a.z, b.x, -(a.x * b.z)), __builtin_fma(a.x, b.y, -(a.y * b.x))};
 }
-__device__ __forceinline__ double dot(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ double dot(const V3& a, const V3& b) {
+#pragma clang fp contract(off)
+    return __builtin_fma(a.z, b.z, __builtin_fma(a.y, b.y, a.x * b.x));
+}
 __device__ __forceinline__ bool finite3(const V3& a) { return isfinite(a.x) && isfinite(a.y) && isfinite(a.z); }
 
 // ---- counter-based RNG: Philox4x32-10 (Salmon et al., SC'11) ------------------------------------
@@ -181,6 +187,82 @@ struct NormalStream {
     }
 };
 
+// identifies one env-step's thermal stream
+struct RngKey {
+    uint64_t seed, env_id;
+    uint32_t env_step;
+};
+
+// ---- where a solve gets its normals from ---------------------------------------------------------------------
+// InlineNormals: the integrating lane runs the stream itself (default).
+// SharedNormals: wave specialisation.  The workgroup has a second wavefront (the producer) that runs the SAME per-env
+// streams one chunk (= one RK4 sub-step / one RK45 attempt) ahead and leaves the normals in LDS; the integrating
+// wavefront only reads them.  The RNG + Box-Muller work (40 % of a thermal RK45 attempt, 65 % of a thermal RK4
+// sub-step) leaves the critical path of the longest lane; the values, their order and therefore the results are
+// identical.  One s_barrier per chunk keeps the two wavefronts in step; loop control is wave-uniform (ballot).
+struct InlineNormals {
+    static constexpr bool kShared = false;
+    NormalStream ns;
+    __device__ __forceinline__ void begin(const RngKey& rk) { ns.init(rk.seed, rk.env_id, rk.env_step, 0u); }
+    __device__ __forceinline__ V3 draw(bool even) { return even ? ns.draw3_even() : ns.draw3_odd(); }
+    __device__ __forceinline__ bool chunk_end(bool lane_continues) { return lane_continues; }
+};
+
+constexpr int SHARED_CHUNK_MAX = 18;     // normals per chunk: RK45 attempt 18, RK4 sub-step 12, Euler 3, RK45 prologue 6
+
+struct SharedNormals {
+    static constexpr bool kShared = true;
+    const float* buf;       // LDS [2][SHARED_CHUNK_MAX][64]
+    volatile int* alive;    // LDS [2]: does the consumer wave continue after chunk `it`?
+    int lane, it, idx;
+    __device__ __forceinline__ void begin(const RngKey&) { it = 0; idx = 0; }
+    __device__ __forceinline__ V3 draw(bool) {
+        const float* b = buf + ((it & 1) * SHARED_CHUNK_MAX + idx) * 64 + lane;
+        idx += 3;
+        return V3{(double)b[0], (double)b[64], (double)b[128]};
+    }
+    // end of the consumer's chunk: wave-uniform decision, published for the producer, then the rendezvous
+    __device__ __forceinline__ bool chunk_end(bool lane_continues) {
+        const bool any = __ballot(lane_continues) != 0ull;
+        alive[it & 1] = any ? 1 : 0;
+        __syncthreads();
+        ++it;
+        idx = 0;
+        return any;
+    }
+};
+
+// The producer wavefront's side of SharedNormals for one solve: chunk 0 has n_first normals, later chunks n_chunk
+// (phase: Euler's single draw per chunk alternates even/odd across chunks).
+__device__ __forceinline__ void produce_normals(float* buf, volatile int* alive, int lane, const RngKey& rk, int n_first,
+                                                int n_chunk) {
+    NormalStream ns;
+    ns.init(rk.seed, rk.env_id, rk.env_step, 0u);
+    int it = 0;
+    bool even = true;
+    auto fill = [&](int slot, int count) {
+        float* b = buf + (slot * SHARED_CHUNK_MAX) * 64 + lane;
+        for (int j = 0; j < count; j += 3) {
+#ifdef STG_EXP_NO_RNG
+            const V3 z{0.25, -0.5, 0.125};
+#else
+            const V3 z = even ? ns.draw3_even() : ns.draw3_odd();
+#endif
+            even = !even;
+            b[(j + 0) * 64] = (float)z.x; b[(j + 1) * 64] = (float)z.y; b[(j + 2) * 64] = (float)z.z;
+        }
+    };
+    fill(0, n_first);
+    __syncthreads();                                   // chunk 0 ready (the consumer waits here too)
+    for (;;) {
+        fill((it + 1) & 1, n_chunk);                   // next chunk, while the consumer works on chunk `it`
+        __syncthreads();                               // = the consumer's chunk_end rendezvous
+        const bool go = alive[it & 1] != 0;
+        ++it;
+        if (!go) break;
+    }
+}
+
 // ---- per-lane constant sets ----------------------------------------------------------------------
 struct SimpleK {            // A1/A2 constants of this lane's device class
     V3 e;
@@ -199,6 +281,9 @@ struct LlgsK {              // A6 constants
 // magnitude of the reference's own intermediates, so overflow happens at the same sub-step.
 template <bool THERMAL, bool AXIS_Z>
 __device__ __forceinline__ V3 simple_rhs(const V3& m, const SimpleK& k, double hk, double kJ, const V3& z) {
+    // every FMA of the fixed-step path is written out and contraction is off, so all instantiations of this source
+    // (one or two wavefronts per workgroup, any launch size) round identically: results do not depend on the partition
+#pragma clang fp contract(off)
     if (AXIS_Z) {
         // easy axis = +z exactly (every factory default, device_factory.py:129-172): t = (my, -mx, 0), H = (0, 0, hz),
         // so the products with the axis' zero components drop out -- 14 fp64 instructions at T = 0 K.  (They only
@@ -266,12 +351,14 @@ __device__ __forceinline__ double vcma_keff(double volt, double ku, double xi, d
 template <bool THERMAL, bool AXIS_Z, bool DEVPHYS>
 __device__ __forceinline__ V3 simple_stage(const V3& m, const SimpleK& k, double kJ, const V3& z, const DevTorque& dv,
                                            bool on) {
+#pragma clang fp contract(off)
     if (!DEVPHYS) return simple_rhs<THERMAL, AXIS_Z>(m, k, k.hk, kJ, z);
     V3 f = simple_rhs<THERMAL, AXIS_Z>(m, k, on ? dv.hk_pulse : k.hk, kJ, z);
     if (dv.any_sot) {
         const double a = on ? dv.sdl : 0.0, b = on ? dv.sfl : 0.0;
         const V3 sxm = cross(dv.sigma, m);
-        f = V3{f.x + (a * sxm.x + b * dv.sigma.x), f.y + (a * sxm.y + b * dv.sigma.y), f.z + (a * sxm.z + b * dv.sigma.z)};
+        f = V3{f.x + __builtin_fma(a, sxm.x, b * dv.sigma.x), f.y + __builtin_fma(a, sxm.y, b * dv.sigma.y),
+               f.z + __builtin_fma(a, sxm.z, b * dv.sigma.z)};
     }
     return f;
 }
@@ -279,6 +366,7 @@ __device__ __forceinline__ V3 simple_stage(const V3& m, const SimpleK& k, double
 // SimpleLLGSSolver._validate_magnetization (simple_solver.py:208-229).
 // returns 0 = normalised, 1 = reset to +z; sets zero_row when the quotient is the all-zero row m/inf.
 __device__ __forceinline__ int simple_validate(V3& m, bool& zero_row) {
+#pragma clang fp contract(off)
     zero_row = false;
     const double s = dot(m, m);
     // non-finite components, or |m| < 1e-12 (s < 1e-24): the reference's "safe default" [0,0,1]
@@ -302,11 +390,6 @@ struct SolveOut {
     bool ok;
 };
 
-struct RngKey {
-    uint64_t seed, env_id;
-    uint32_t env_step;
-};
-
 // Optional trajectory recorder (stg_solve_traj): rows are written with env index fastest.
 struct Recorder {
     double* t;       // [cap][N]
@@ -327,13 +410,15 @@ struct Recorder {
 };
 
 // A3 + A4 + A5: RobustLLGSSolver.solve -> SimpleLLGSSolver.solve, METHOD 0 = rk4, 1 = euler.
-template <int METHOD, bool THERMAL, bool RECORD, bool AXIS_Z, bool DEVPHYS>
+template <int METHOD, bool THERMAL, bool RECORD, bool AXIS_Z, bool DEVPHYS, class NSRC>
 __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double T, const SimpleK& k, double pol,
                                                  double msv, bool class_valid, double temperature, double max_step,
-                                                 const RngKey& rk, const Recorder& rec, const DevTorque& dv) {
+                                                 const RngKey& rk, const Recorder& rec, const DevTorque& dv, NSRC& ns) {
+#pragma clang fp contract(off)
     SolveOut o{m0, 0, 0, 0, false};
     // robust_solver.py:152-190 (_validate_inputs); any failure ends in the fallback result (:140-150)
-    if (validation_rejects(m0) || !(T > 0.0) || !class_valid || !(temperature > 0.0)) return o;
+    const bool rejected_in = validation_rejects(m0) || !(T > 0.0) || !class_valid || !(temperature > 0.0);
+    if (!NSRC::kShared && rejected_in) return o;
     V3 m = m0;
     bool zr;
     int resets = simple_validate(m, zr);                                   // simple_solver.py:119
@@ -342,6 +427,8 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
     int n = (int)(T / dt);
     n = n < 10 ? 10 : n;
     dt = T / (double)n;
+    // SharedNormals: every lane of the wavefront walks the (wave-uniform) chunk loop; a rejected lane has no sub-steps
+    if (NSRC::kShared && rejected_in) n = 0;
     o.n = n;
     o.work = n;
     const double half_dt = 0.5 * dt, sixth_dt = dt / 6.0;
@@ -358,43 +445,47 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
     const double kJ4_last = on4_last ? kJ : 0.0;
     bool fail = false;
     const V3 zero{0.0, 0.0, 0.0};
-    NormalStream ns;
-    if (THERMAL) ns.init(rk.seed, rk.env_id, rk.env_step, 0u);
+    if (THERMAL) ns.begin(rk);
     if (RECORD) rec.put(0, 0.0, m, 0.0);
-    for (int i = 0; i < n; ++i) {
+    // per-lane trip count n; with SharedNormals the loop is wave-uniform (lanes past their n idle inside the body)
+    for (int i = 0; NSRC::kShared || i < n; ++i) {
+      if (i < n) {
         const bool last = (i == n - 1);
         const double kJ2 = last ? kJ2_last : kJ, kJ4 = last ? kJ4_last : kJ;
         const bool on2 = !last || on2_last, on4 = !last || on4_last;
         V3 mn;
         if (METHOD == 1) {
             V3 z0 = zero;
-            if (THERMAL) z0 = (i & 1) ? ns.draw3_odd() : ns.draw3_even();
+            if (THERMAL) z0 = ns.draw((i & 1) == 0);
             const V3 f = simple_stage<THERMAL, AXIS_Z, DEVPHYS>(m, k, kJ, z0, dv, true);
-            mn = V3{m.x + dt * f.x, m.y + dt * f.y, m.z + dt * f.z};      // simple_solver.py:275-276
+            mn = V3{__builtin_fma(dt, f.x, m.x), __builtin_fma(dt, f.y, m.y), __builtin_fma(dt, f.z, m.z)};   // simple_solver.py:275-276
         } else {
             V3 z0 = zero, z1 = zero, z2 = zero, z3 = zero;
             if (THERMAL) {   // 12 normals = 6 Box-Muller pairs per sub-step
-                z0 = ns.draw3_even(); z1 = ns.draw3_odd(); z2 = ns.draw3_even(); z3 = ns.draw3_odd();
+                z0 = ns.draw(true); z1 = ns.draw(false); z2 = ns.draw(true); z3 = ns.draw(false);
             }
             const V3 f1 = simple_stage<THERMAL, AXIS_Z, DEVPHYS>(m, k, kJ, z0, dv, true);
-            const V3 y2{m.x + half_dt * f1.x, m.y + half_dt * f1.y, m.z + half_dt * f1.z};
+            const V3 y2{__builtin_fma(half_dt, f1.x, m.x), __builtin_fma(half_dt, f1.y, m.y), __builtin_fma(half_dt, f1.z, m.z)};
             const V3 f2 = simple_stage<THERMAL, AXIS_Z, DEVPHYS>(y2, k, kJ2, z1, dv, on2);
-            const V3 y3{m.x + half_dt * f2.x, m.y + half_dt * f2.y, m.z + half_dt * f2.z};
+            const V3 y3{__builtin_fma(half_dt, f2.x, m.x), __builtin_fma(half_dt, f2.y, m.y), __builtin_fma(half_dt, f2.z, m.z)};
             const V3 f3 = simple_stage<THERMAL, AXIS_Z, DEVPHYS>(y3, k, kJ2, z2, dv, on2);
-            const V3 y4{m.x + dt * f3.x, m.y + dt * f3.y, m.z + dt * f3.z};
+            const V3 y4{__builtin_fma(dt, f3.x, m.x), __builtin_fma(dt, f3.y, m.y), __builtin_fma(dt, f3.z, m.z)};
             const V3 f4 = simple_stage<THERMAL, AXIS_Z, DEVPHYS>(y4, k, kJ4, z3, dv, on4);
             // m + (k1 + 2 k2 + 2 k3 + k4)/6 with k = dt*f                  simple_solver.py:290-295
-            mn = V3{m.x + sixth_dt * ((f1.x + 2.0 * f2.x) + (2.0 * f3.x + f4.x)),
-                    m.y + sixth_dt * ((f1.y + 2.0 * f2.y) + (2.0 * f3.y + f4.y)),
-                    m.z + sixth_dt * ((f1.z + 2.0 * f2.z) + (2.0 * f3.z + f4.z))};
+            mn = V3{__builtin_fma(sixth_dt, __builtin_fma(2.0, f2.x, f1.x) + __builtin_fma(2.0, f3.x, f4.x), m.x),
+                    __builtin_fma(sixth_dt, __builtin_fma(2.0, f2.y, f1.y) + __builtin_fma(2.0, f3.y, f4.y), m.y),
+                    __builtin_fma(sixth_dt, __builtin_fma(2.0, f2.z, f1.z) + __builtin_fma(2.0, f3.z, f4.z), m.z)};
         }
         resets += simple_validate(mn, zr);                                 // simple_solver.py:168
         fail |= zr;                                                        // robust_solver.py:192-205
         m = mn;
         if (RECORD) rec.put(i + 1, last ? T : mul_x((double)(i + 1), dt), m, 0.0);
+      }
+      if (NSRC::kShared && !ns.chunk_end(i + 1 < n)) break;
     }
-    o.resets = resets;
-    if (fail) return o;
+    const bool rejected_shared = NSRC::kShared && rejected_in;
+    o.resets = rejected_shared ? 0 : resets;
+    if (fail || rejected_shared) return o;
     o.m = m;
     o.ok = true;
     return o;
@@ -452,11 +543,11 @@ __device__ __forceinline__ double llgs_energy(const V3& m, const LlgsEnergyK& k)
 __device__ __forceinline__ double rms3(const V3& a) { return sqrt(dot(a, a)) / 1.7320508075688772; }   // common.py:63-65
 
 // A7 (+A8 when RECORD): scipy solve_ivp(RK45) as LLGSSolver.solve drives it.
-template <bool THERMAL, bool RECORD, bool AXIS_Z>
+template <bool THERMAL, bool RECORD, bool AXIS_Z, class NSRC>
 __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T, const LlgsK& k, double beta,
                                                double betap, double rtol, double atol, double max_step,
                                                int64_t max_attempts, const RngKey& rk, const Recorder& rec,
-                                               const LlgsEnergyK& ek) {
+                                               const LlgsEnergyK& ek, NSRC& ns) {
     // Dormand-Prince tableau (rk.py:380-391)
     constexpr double A21 = 1.0 / 5;
     constexpr double A31 = 3.0 / 40, A32 = 9.0 / 40;
@@ -471,13 +562,12 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
     const bool useJ = !(fabs(J) < 1e-12);                                   // llgs_solver.py:222
     const double bJ = useJ ? beta * J : 0.0, bpJ = useJ ? betap * J : 0.0;
     const V3 zero{0.0, 0.0, 0.0};
-    NormalStream ns;
-    if (THERMAL) ns.init(rk.seed, rk.env_id, rk.env_step, 0u);
+    if (THERMAL) ns.begin(rk);
     // RHS call with the pulse gate of spin_torque_env.py:442-443; EVEN selects the normal-stream phase (calls alternate)
     auto fun = [&](double t, const V3& y, bool even) -> V3 {
         const bool on = t <= T;
         V3 z = zero;
-        if (THERMAL) z = even ? ns.draw3_even() : ns.draw3_odd();
+        if (THERMAL) z = ns.draw(even);
         return llgs_rhs<THERMAL, AXIS_Z>(y, k, on ? bJ : 0.0, on ? bpJ : 0.0, z);
     };
     const double n0 = rsqrt_fast(dot(m0, m0));                              // llgs_solver.py:76
@@ -516,8 +606,18 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
     int64_t attempts = 0;
     double min_step = min_step_at(t);
     h_abs = h_abs > max_step ? max_step : (h_abs < min_step ? min_step : h_abs);          // rk.py:121-126
-    while (t != T) {
-        if (h_abs < min_step || attempts >= max_attempts) { ok = false; break; }          // rk.py:132-133 (+ budget)
+    // SharedNormals: the prologue's two RHS calls were chunk 0; every attempt is one further chunk and the loop is
+    // wave-uniform (a finished lane idles until the wavefront's last lane is through)
+    bool active = (t != T);
+    bool wave_go = true;
+    if (NSRC::kShared) wave_go = ns.chunk_end(active);
+    if (wave_go)
+    for (;;) {
+      if (!NSRC::kShared && !active) break;
+      if (active) {
+        if (h_abs < min_step || attempts >= max_attempts) { ok = false; active = false; }  // rk.py:132-133 (+ budget)
+      }
+      if (active) {
         ++attempts;
         double t_new = add_x(t, h_abs);
         if (t_new - T > 0.0) t_new = T;
@@ -571,6 +671,9 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
             h_abs *= g;
             rejected = true;
         }
+        active = (t != T);
+      }
+      if (NSRC::kShared && !ns.chunk_end(active)) break;
     }
     o.n = npts - 1;
     o.work = attempts;
@@ -582,6 +685,7 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
 // A9: compute_resistance.  ref = normalised reference layer.
 __device__ __forceinline__ double resistance(const V3& m_in, int dev_type, double r_p, double r_ap, double tmr,
                                              const V3& ref, double r_series) {
+#pragma clang fp contract(off)
     if (dev_type == 0) {
         const double mn = sqrt(dot(m_in, m_in));               // base_device.py:112-116
         const V3 m{m_in.x / mn, m_in.y / mn, m_in.z / mn};

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspintorque_hip.so")
+# STG_HIP_LIBRARY points at another build of the same library (A/B runs of kernel changes); the default is the in-tree one
+LIB_PATH = os.environ.get("STG_HIP_LIBRARY") or os.path.join(_HERE, "libspintorque_hip.so")
 
 STG_MAX_TARGETS = 8
 STG_MAX_CLASSES = 64
@@ -24,7 +25,7 @@ class StgConfig(C.Structure):
         ("n_targets", C.c_int32), ("max_current", C.c_double), ("max_duration", C.c_double),
         ("success_threshold", C.c_double), ("energy_penalty_weight", C.c_double),
         ("targets", (C.c_double * 3) * STG_MAX_TARGETS), ("seed", C.c_uint64), ("max_attempts", C.c_int64),
-        ("skip_done", C.c_int32), ("torque_model", C.c_int32), ("reserved", C.c_int32), ("lane_sort", C.c_int32),
+        ("skip_done", C.c_int32), ("torque_model", C.c_int32), ("wave_spec", C.c_int32), ("lane_sort", C.c_int32),
     ]
 
 

@@ -36,6 +36,7 @@ class EnvConfig:
     skip_done: bool = False
     torque_model: str = "reference"           # 'reference' (the env's type-agnostic RHS) | 'device' (opt-in)
     lane_sort: Optional[bool] = None          # duration-sorted lane schedule: None = automatic, True/False = force
+    wave_spec: Optional[bool] = None          # producer/consumer wavefront pairs (thermal): None = automatic
 
     def to_abi(self) -> "_lib.StgConfig":
         if self.solver not in _lib.SOLVERS:
@@ -61,6 +62,7 @@ class EnvConfig:
             raise ValueError("torque_model must be 'reference' or 'device'")
         c.torque_model = int(self.torque_model == "device")
         c.lane_sort = 0 if self.lane_sort is None else (1 if self.lane_sort else -1)
+        c.wave_spec = 0 if self.wave_spec is None else (1 if self.wave_spec else -1)
         return c
 
 

@@ -93,7 +93,7 @@ class SpinTorqueVecEnv:
                  include_thermal_fluctuations: bool = True, success_threshold: float = 0.9,
                  energy_penalty_weight: float = 0.1, solver: str = "rk4", seed: Optional[int] = None,
                  autoreset: bool = False, skip_done: bool = False, device_index: int = 0, env_id0: int = 0,
-                 max_attempts: int = 200_000, lane_sort: Optional[bool] = None, torque_model: str = "reference",
+                 max_attempts: int = 200_000, lane_sort: Optional[bool] = None, wave_spec: Optional[bool] = None, torque_model: str = "reference",
                  backend=None):
         self.num_envs = int(num_envs)
         factory = DeviceFactory()
@@ -119,7 +119,7 @@ class SpinTorqueVecEnv:
                              max_duration=max_duration, success_threshold=success_threshold,
                              energy_penalty_weight=energy_penalty_weight, target_states=[list(t) for t in targets],
                              seed=int(self._rng.integers(0, 2**63 - 1)) if seed is None else int(seed),
-                             max_attempts=max_attempts, skip_done=skip_done, lane_sort=lane_sort,
+                             max_attempts=max_attempts, skip_done=skip_done, lane_sort=lane_sort, wave_spec=wave_spec,
                              torque_model=torque_model)
         self.autoreset = bool(autoreset)
         # `backend` is a test seam: a class/callable with HipBackend's constructor signature (tests inject the CPU

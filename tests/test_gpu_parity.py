@@ -630,6 +630,42 @@ def test_kernel_variant_matrix_vs_oracle(stg, solver):
     print(solver, "variant matrix worst |dm| =", worst)
 
 
+@pytest.mark.parametrize("solver", ["rk4", "euler", "rk45"])
+def test_wave_specialised_kernels_bit_identical(stg, solver):
+    """The producer/consumer variant of the thermal kernels (a second wavefront runs the envs' normal streams ahead into
+    LDS) draws the same values in the same order: every output must be bit-identical to the one-wavefront kernels, over
+    ragged sizes, class tables, skip_done wavefronts that have nothing to integrate, fused steps and auto-reset."""
+    n, K = 1000, 3                            # 15 full wavefronts + one ragged
+    vol = 9.7e-6 if solver == "rk45" else 8.75e-11
+    rng = np.random.default_rng(11)
+    acts = np.stack([_uniform_actions(2e6, 1e-10, 4e-10)(rng, n, s) for s in range(K)])     # [K,N,2]
+    acts[0, 5, 0] = np.nan                    # bad action in a wave of good ones
+    acts[1, 64:128, 1] = 1e-12                # a wavefront of minimum-duration pulses
+    for multi in (False, True):
+        for mode in ("plain", "skip_done", "autoreset"):
+            if multi:
+                kw = dict(device_type=["stt_mram", "vcma_mram"],
+                          device_params=[stt_default_params(volume=vol),
+                                         vcma_default_params(polarization=0.6, volume=vol * 0.8)],
+                          class_index=(np.arange(n) % 2).astype(np.uint8))
+            else:
+                kw = dict(device_params=stt_default_params(volume=vol))
+            kw.update(include_thermal_fluctuations=True, solver=solver, seed=21, max_steps=2 if mode != "plain" else 100,
+                      skip_done=(mode == "skip_done"), autoreset=(mode == "autoreset"))
+            outs = []
+            for ws in (False, True):
+                env = stg.SpinTorqueVecEnv(n, wave_spec=ws, **kw)
+                env.reset(seed=4)
+                o1, r1, te1, tr1, i1 = env.step(torch.from_numpy(acts[0]))
+                om, rm, tem, trm, im = env.step_many(torch.from_numpy(acts))
+                st = env.get_state()
+                outs.append([o1.clone(), i1["reward_f64"].clone(), te1.clone(), i1["status"].clone(), om.clone(),
+                             im["reward_f64"].clone(), tem.clone(), trm.clone(), st["m"].clone(), st["step_count"].clone()])
+                env.close()
+            for x, y in zip(*outs):
+                assert torch.equal(x, y), (solver, multi, mode)
+
+
 def test_g12_device_terms_kernel_vs_reference_formulas(stg, golden):
     from test_oracle_golden import G12_SOT, G12_VCMA
     g = golden("G12_device_terms")
