@@ -10,6 +10,7 @@
 // workgroup and each lane reads its class row from there.
 #include "../../include/spintorque_hip.h"
 #include "stg_physics.hpp"
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 
@@ -93,8 +94,8 @@ __device__ __forceinline__ SimpleK load_simple(const double* r) {
     return SimpleK{V3{r[C_EX], r[C_EY], r[C_EZ]}, r[C_HK], r[C_MS], r[C_ALPHA], r[C_GEFF], r[C_HS_SIMPLE]};
 }
 __device__ __forceinline__ LlgsK load_llgs(const double* r) {
-    return LlgsK{V3{r[C_RX], r[C_RY], r[C_RZ]}, V3{r[C_DX], r[C_DY], r[C_DZ]}, r[C_HK], r[C_HEX], r[C_ALPHA], r[C_GAMMA],
-                 r[C_HS_LLGS]};
+    return make_llgs(V3{r[C_RX], r[C_RY], r[C_RZ]}, V3{r[C_DX], r[C_DY], r[C_DZ]}, r[C_HK], r[C_HEX], r[C_ALPHA], r[C_GAMMA],
+                     r[C_HS_LLGS]);
 }
 __device__ __forceinline__ LlgsEnergyK load_energy(const double* r) {
     return LlgsEnergyK{r[C_KUV], r[C_EDEMAG], V3{r[C_RX], r[C_RY], r[C_RZ]}, V3{r[C_NX], r[C_NY], r[C_NZ]}};
@@ -223,7 +224,11 @@ __global__ void __launch_bounds__(PC ? 128 : 64) stg_step_kernel(const StepArgs 
 #pragma clang fp contract(off)
     static_assert(!PC || THERMAL, "wave specialisation only exists for the thermal kernels");
     __shared__ double s_tab[MULTI ? STG_MAX_CLASSES * C_COUNT : 1];
-    __shared__ float s_norm[PC ? 2 * SHARED_CHUNK_MAX * 64 : 1];
+    // normals ring of the wave-specialised kernels: RK45 hands over finished fields (double), the fixed-step solvers raw
+    // normals (float)
+    constexpr bool FIELD = SOLVER == STG_SOLVER_RK45;
+    using NT = typename std::conditional<FIELD, double, float>::type;
+    __shared__ NT s_norm[PC ? 2 * SHARED_CHUNK_MAX * 64 : 1];
     __shared__ int s_alive[2], s_go[2];
     __shared__ uint32_t s_rng[PC ? 64 : 1];
     const int lane = PC ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
@@ -241,11 +246,12 @@ __global__ void __launch_bounds__(PC ? 128 : 64) stg_step_kernel(const StepArgs 
         // producer wavefront: per env-step, wait for the consumer's stream position, then stay one chunk ahead
         constexpr int n_first = SOLVER == STG_SOLVER_RK45 ? 6 : (SOLVER == STG_SOLVER_RK4 ? 12 : 3);
         constexpr int n_chunk = SOLVER == STG_SOLVER_RK45 ? 18 : n_first;
+        const double ghs = FIELD ? load_llgs(row).ghs : 0.0;
         for (int k = 0; k < a.K; ++k) {
             __syncthreads();                                       // H1: s_rng / s_go[k & 1] published
             if (!s_go[k & 1]) continue;
             const RngKey rk{a.c.seed, env_id, s_rng[lane]};
-            produce_normals(s_norm, s_alive, lane, rk, n_first, n_chunk);
+            produce_normals<NT, FIELD>(s_norm, s_alive, lane, rk, n_first, n_chunk, ghs);
         }
         return;
     }
@@ -270,7 +276,7 @@ __global__ void __launch_bounds__(PC ? 128 : 64) stg_step_kernel(const StepArgs 
         uint8_t st;
         double reward, energy = 0.0;
         bool is_success, truncated;
-        SharedNormals shared{s_norm, s_alive, lane, 0, 0};
+        SharedNormalsT<NT, FIELD> shared{s_norm, s_alive, lane, 0, 0};
         InlineNormals inl;
         if (PC) {
             const bool wave_go = __ballot(!(a.c.skip_done && done)) != 0ull;

@@ -118,6 +118,12 @@ __device__ __forceinline__ double dot(const V3& a, const V3& b) {
 #pragma clang fp contract(off)
     return __builtin_fma(a.z, b.z, __builtin_fma(a.y, b.y, a.x * b.x));
 }
+// thermal field of one RHS call from its three normals (separate roundings: the producer wavefront of the
+// wave-specialised kernels forms exactly this product before handing it over)
+__device__ __forceinline__ V3 scale3(double c, const V3& z) {
+#pragma clang fp contract(off)
+    return V3{c * z.x, c * z.y, c * z.z};
+}
 __device__ __forceinline__ bool finite3(const V3& a) { return isfinite(a.x) && isfinite(a.y) && isfinite(a.z); }
 
 // ---- counter-based RNG: Philox4x32-10 (Salmon et al., SC'11) ------------------------------------
@@ -201,7 +207,7 @@ struct RngKey {
 // sub-step) leaves the critical path of the longest lane; the values, their order and therefore the results are
 // identical.  One s_barrier per chunk keeps the two wavefronts in step; loop control is wave-uniform (ballot).
 struct InlineNormals {
-    static constexpr bool kShared = false;
+    static constexpr bool kShared = false, kScaled = false;
     NormalStream ns;
     __device__ __forceinline__ void begin(const RngKey& rk) { ns.init(rk.seed, rk.env_id, rk.env_step, 0u); }
     __device__ __forceinline__ V3 draw(bool even) { return even ? ns.draw3_even() : ns.draw3_odd(); }
@@ -210,14 +216,18 @@ struct InlineNormals {
 
 constexpr int SHARED_CHUNK_MAX = 18;     // normals per chunk: RK45 attempt 18, RK4 sub-step 12, Euler 3, RK45 prologue 6
 
-struct SharedNormals {
-    static constexpr bool kShared = true;
-    const float* buf;       // LDS [2][SHARED_CHUNK_MAX][64]
+// T = float: raw normals (fixed-step solvers, whose producer is the critical wavefront and should do no extra work);
+// T = double, SCALED: the finished thermal field c * z (RK45, whose producer has slack: the integrating wavefront
+// saves the conversions and the scaling of every RHS call).
+template <typename T, bool SCALED>
+struct SharedNormalsT {
+    static constexpr bool kShared = true, kScaled = SCALED;
+    const T* buf;           // LDS [2][SHARED_CHUNK_MAX][64]
     volatile int* alive;    // LDS [2]: does the consumer wave continue after chunk `it`?
     int lane, it, idx;
     __device__ __forceinline__ void begin(const RngKey&) { it = 0; idx = 0; }
     __device__ __forceinline__ V3 draw(bool) {
-        const float* b = buf + ((it & 1) * SHARED_CHUNK_MAX + idx) * 64 + lane;
+        const T* b = buf + ((it & 1) * SHARED_CHUNK_MAX + idx) * 64 + lane;
         idx += 3;
         return V3{(double)b[0], (double)b[64], (double)b[128]};
     }
@@ -232,24 +242,26 @@ struct SharedNormals {
     }
 };
 
-// The producer wavefront's side of SharedNormals for one solve: chunk 0 has n_first normals, later chunks n_chunk
-// (phase: Euler's single draw per chunk alternates even/odd across chunks).
-__device__ __forceinline__ void produce_normals(float* buf, volatile int* alive, int lane, const RngKey& rk, int n_first,
-                                                int n_chunk) {
+// The producer wavefront's side for one solve: chunk 0 has n_first normals, later chunks n_chunk; calls alternate
+// between the even and odd phase of the stream across chunk boundaries, exactly as the integrator's calls do.
+template <typename T, bool SCALED>
+__device__ __forceinline__ void produce_normals(T* buf, volatile int* alive, int lane, const RngKey& rk, int n_first,
+                                                int n_chunk, double c) {
     NormalStream ns;
     ns.init(rk.seed, rk.env_id, rk.env_step, 0u);
     int it = 0;
     bool even = true;
     auto fill = [&](int slot, int count) {
-        float* b = buf + (slot * SHARED_CHUNK_MAX) * 64 + lane;
+        T* b = buf + (slot * SHARED_CHUNK_MAX) * 64 + lane;
         for (int j = 0; j < count; j += 3) {
 #ifdef STG_EXP_NO_RNG
-            const V3 z{0.25, -0.5, 0.125};
+            V3 z{0.25, -0.5, 0.125};
 #else
-            const V3 z = even ? ns.draw3_even() : ns.draw3_odd();
+            V3 z = even ? ns.draw3_even() : ns.draw3_odd();
 #endif
+            if (SCALED) z = scale3(c, z);
             even = !even;
-            b[(j + 0) * 64] = (float)z.x; b[(j + 1) * 64] = (float)z.y; b[(j + 2) * 64] = (float)z.z;
+            b[(j + 0) * 64] = (T)z.x; b[(j + 1) * 64] = (T)z.y; b[(j + 2) * 64] = (T)z.z;
         }
     };
     fill(0, n_first);
@@ -268,10 +280,21 @@ struct SimpleK {            // A1/A2 constants of this lane's device class
     V3 e;
     double hk, ms, alpha, geff, hs;
 };
-struct LlgsK {              // A6 constants
-    V3 r, d;
-    double hk, hex, alpha, gamma, hs;
+struct LlgsK {              // A6 constants, with -gamma folded in (dm0 = -gamma m x H = m x (-gamma H))
+    V3 r;                   // raw easy axis
+    V3 gd;                  // -gamma * (-ms * demag_factors)
+    double ghk, ghex;       // -gamma * hk, -gamma * hex
+    double alpha;
+    double ghs;             // -gamma * Brown strength: the thermal field enters as ghs * z
+    double gz;              // AXIS_Z: -gamma * (hk r_z^2 - ms N_z), so that -gamma H_z(det) = gz * m_z
 };
+// builds the folded constants from the class-table values (once per lane per launch)
+__device__ __forceinline__ LlgsK make_llgs(const V3& r, const V3& d, double hk, double hex, double alpha, double gamma, double hs) {
+#pragma clang fp contract(off)
+    const double ng = -gamma;
+    return LlgsK{r, V3{ng * d.x, ng * d.y, ng * d.z}, ng * hk, ng * hex, alpha, ng * hs, ng * ((hk * r.z) * r.z + d.z)};
+}
+
 
 // A1 + A2: SimpleLLGSSolver._compute_dmdt with h_applied = 0 (simple_solver.py:297-388), regrouped:
 //   H = c e + d z^ (+ hs z),  c = hk (m.e),  d = -ms m_z
@@ -491,35 +514,32 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
     return o;
 }
 
-// A6: LLGSSolver.solve::llgs_rhs.  bJ = beta*J, bpJ = beta'*J (0 when |J| < 1e-12 or the pulse is over).
-// AXIS_Z: raw easy axis = (0,0,rz) and demag factors = (0,0,Nz) (every factory default): H = hex*m + (0,0,g) (+ hs z).
+// A6: LLGSSolver.solve::llgs_rhs.  bJ = beta*J, bpJ = beta'*J (0 when |J| < 1e-12 or the pulse is over); ht = ghs * z is the
+// thermal field of this call already times -gamma (scale3).  With G = -gamma H:  dm = m x G + alpha m x (m x G) + torques.
+// AXIS_Z: raw easy axis = (0,0,rz) and demag factors = (0,0,Nz) (every factory default): G = ghex*m + (0,0,gz m_z) + ht.
 // The exchange placeholder hex*m (llgs_solver.py:205-209) is parallel to m, so it cancels in m x H up to a rounding
 // residue of ~1e-16 * hex (hex ~ 4e-6 A/m against H_k ~ 2.4e6 A/m) and is dropped there; the general form keeps it.
 template <bool THERMAL, bool AXIS_Z>
-__device__ __forceinline__ V3 llgs_rhs(const V3& y, const LlgsK& k, double bJ, double bpJ, const V3& z) {
+__device__ __forceinline__ V3 llgs_rhs(const V3& y, const LlgsK& k, double bJ, double bpJ, const V3& ht) {
+    // |y| > 1e-12 -> y/|y|, else +z (llgs_solver.py:97-101).  |y| stays within 1e-6 of 1 on this path, so the
+    // degenerate case is handled behind a wave-uniform branch that is never taken in practice.
     const double ss = dot(y, y);
-    V3 m{0.0, 0.0, 1.0};
-    if (ss > 1e-24) {                                                      // |y| > 1e-12, llgs_solver.py:97-101
-        const double inv = rsqrt_fast(ss);
-        m = V3{y.x * inv, y.y * inv, y.z * inv};
-    }
-    V3 mxh;
+    const double inv = rsqrt_fast(ss);
+    V3 m{y.x * inv, y.y * inv, y.z * inv};
+    const bool unit = ss > 1e-24;
+    if (__builtin_expect(__ballot(!unit) != 0ull, 0)) m = V3{unit ? m.x : 0.0, unit ? m.y : 0.0, unit ? m.z : 1.0};
+    V3 dm;                                                                  // m x G
     if (AXIS_Z) {
-        const double g = __builtin_fma(k.hk * k.r.z, k.r.z * m.z, k.d.z * m.z);   // hk (m.r) r_z - ms N_z m_z
-        if (THERMAL) {
-            const V3 h{k.hs * z.x, k.hs * z.y, __builtin_fma(k.hs, z.z, g)};
-            mxh = cross(m, h);
-        } else {
-            mxh = V3{m.y * g, -(m.x * g), 0.0};
-        }
+        const double g = k.gz * m.z;
+        if (THERMAL) dm = cross(m, V3{ht.x, ht.y, ht.z + g});
+        else dm = V3{m.y * g, -(m.x * g), 0.0};
     } else {
-        const double c = k.hk * dot(m, k.r);
-        V3 h{(c * k.r.x + k.d.x * m.x) + k.hex * m.x, (c * k.r.y + k.d.y * m.y) + k.hex * m.y,
-             (c * k.r.z + k.d.z * m.z) + k.hex * m.z};
-        if (THERMAL) h = V3{h.x + k.hs * z.x, h.y + k.hs * z.y, h.z + k.hs * z.z};        // llgs_solver.py:111-113
-        mxh = cross(m, h);
+        const double c = k.ghk * dot(m, k.r);
+        V3 h{(c * k.r.x + k.gd.x * m.x) + k.ghex * m.x, (c * k.r.y + k.gd.y * m.y) + k.ghex * m.y,
+             (c * k.r.z + k.gd.z * m.z) + k.ghex * m.z};
+        if (THERMAL) h = V3{h.x + ht.x, h.y + ht.y, h.z + ht.z};                            // llgs_solver.py:111-113
+        dm = cross(m, h);
     }
-    V3 dm{-k.gamma * mxh.x, -k.gamma * mxh.y, -k.gamma * mxh.z};
     V3 mxdm;
     if (AXIS_Z && !THERMAL) mxdm = V3{-(m.z * dm.y), m.z * dm.x, __builtin_fma(m.x, dm.y, -(m.y * dm.x))};   // dm.z = 0
     else mxdm = cross(m, dm);
@@ -566,21 +586,23 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
     // RHS call with the pulse gate of spin_torque_env.py:442-443; EVEN selects the normal-stream phase (calls alternate)
     auto fun = [&](double t, const V3& y, bool even) -> V3 {
         const bool on = t <= T;
-        V3 z = zero;
-        if (THERMAL) z = ns.draw(even);
-        return llgs_rhs<THERMAL, AXIS_Z>(y, k, on ? bJ : 0.0, on ? bpJ : 0.0, z);
+        V3 ht = zero;
+        if (THERMAL) ht = NSRC::kScaled ? ns.draw(even) : scale3(k.ghs, ns.draw(even));
+        return llgs_rhs<THERMAL, AXIS_Z>(y, k, on ? bJ : 0.0, on ? bpJ : 0.0, ht);
     };
     const double n0 = rsqrt_fast(dot(m0, m0));                              // llgs_solver.py:76
     V3 y{m0.x * n0, m0.y * n0, m0.z * n0};
     double t = 0.0;
     int32_t npts = 0;
+    // every accepted point is renormalised on output (llgs_solver.py:152-153); without a recorder only the last one is
+    // ever read, so it is formed once after the loop
     auto emit = [&]() {
-        const double inv = rsqrt_fast(dot(y, y));                           // llgs_solver.py:152-153
+        const double inv = rsqrt_fast(dot(y, y));
         o.m = V3{y.x * inv, y.y * inv, y.z * inv};
         if (RECORD) rec.put(npts, t, o.m, rec.e ? llgs_energy(o.m, ek) : 0.0);
         ++npts;
     };
-    emit();
+    if (RECORD) emit(); else ++npts;
     V3 f = fun(t, y, true);
     double h_abs;
     {   // select_initial_step (common.py:68-134), order = error_estimator_order = 4
@@ -654,27 +676,29 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
         const V3 q{ev.x * rcp_fast(sc.x), ev.y * rcp_fast(sc.y), ev.z * rcp_fast(sc.z)};
         const double err2 = dot(q, q) * (1.0 / 3.0);
         const double err = err2;      // compared against squared thresholds below
-        // 0.9 * err^-0.2 saturates at MAX_FACTOR = 10 for err <= 0.09^5 and at MIN_FACTOR = 0.2 for err >= 4.5^5
-        if (err < 1.0) {
-            double factor = (err <= 3.486784401e-11) ? 10.0 : fmin(10.0, 0.9 * inv_tenth_root(err));   // also err == 0
-            if (rejected) factor = fmin(1.0, factor);
-            h_abs *= factor;
-            // step accepted: advance, record, and do the next step()'s prologue
-            t = t_new; y = y_new; f = f_new;
-            emit();
-            rejected = false;
-            min_step = min_step_at(t);
-            h_abs = h_abs > max_step ? max_step : (h_abs < min_step ? min_step : h_abs);
-        } else {
-            // NaN error norms land here too (nan < 1 is False), as in SciPy; fmax(0.2, NaN) = 0.2
-            const double g = (err >= 3405062.8916015625) ? 0.2 : fmax(0.2, 0.9 * inv_tenth_root(err));
-            h_abs *= g;
-            rejected = true;
-        }
+        // Controller (rk.py:158-181), branch-free: both outcomes share err^-0.2 and differ in a handful of selects.
+        // 0.9 * err^-0.2 saturates at MAX_FACTOR = 10 for err <= 0.09^5 and at MIN_FACTOR = 0.2 for err >= 4.5^5 (err is
+        // the SQUARED norm here); NaN error norms reject (nan < 1 is False) with fmax(0.2, NaN) = 0.2, as in SciPy.
+        const bool acc = err < 1.0;
+        const double r9 = 0.9 * inv_tenth_root(err);
+        double fa = (err <= 3.486784401e-11) ? 10.0 : fmin(10.0, r9);                      // also err == 0
+        fa = rejected ? fmin(1.0, fa) : fa;
+        const double fr = (err >= 3405062.8916015625) ? 0.2 : fmax(0.2, r9);
+        h_abs *= acc ? fa : fr;
+        // an accepted attempt advances, records, and does the next step()'s prologue
+        t = acc ? t_new : t;
+        y = V3{acc ? y_new.x : y.x, acc ? y_new.y : y.y, acc ? y_new.z : y.z};
+        f = V3{acc ? f_new.x : f.x, acc ? f_new.y : f.y, acc ? f_new.z : f.z};
+        if (RECORD) { if (acc) emit(); } else npts += acc ? 1 : 0;
+        rejected = !acc;
+        min_step = min_step_at(t);                                                         // unchanged t -> unchanged value
+        const double hc = h_abs > max_step ? max_step : (h_abs < min_step ? min_step : h_abs);
+        h_abs = acc ? hc : h_abs;
         active = (t != T);
       }
       if (NSRC::kShared && !ns.chunk_end(active)) break;
     }
+    if (!RECORD) { emit(); --npts; }
     o.n = npts - 1;
     o.work = attempts;
     o.ok = ok;

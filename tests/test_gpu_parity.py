@@ -642,7 +642,9 @@ def test_wave_specialised_kernels_bit_identical(stg, solver):
     acts[0, 5, 0] = np.nan                    # bad action in a wave of good ones
     acts[1, 64:128, 1] = 1e-12                # a wavefront of minimum-duration pulses
     for multi in (False, True):
-        for mode in ("plain", "skip_done", "autoreset"):
+        for mode in ("plain", "skip_done", "autoreset", "budget"):
+            if mode == "budget" and solver != "rk45":
+                continue                      # attempt budget: lanes give up mid-loop while their wavefront goes on
             if multi:
                 kw = dict(device_type=["stt_mram", "vcma_mram"],
                           device_params=[stt_default_params(volume=vol),
@@ -652,6 +654,8 @@ def test_wave_specialised_kernels_bit_identical(stg, solver):
                 kw = dict(device_params=stt_default_params(volume=vol))
             kw.update(include_thermal_fluctuations=True, solver=solver, seed=21, max_steps=2 if mode != "plain" else 100,
                       skip_done=(mode == "skip_done"), autoreset=(mode == "autoreset"))
+            if mode == "budget":
+                kw.update(max_attempts=150)   # ~0.13 ns worth of attempts: most lanes end as STG_STATUS_NOOP
             outs = []
             for ws in (False, True):
                 env = stg.SpinTorqueVecEnv(n, wave_spec=ws, **kw)
@@ -664,6 +668,9 @@ def test_wave_specialised_kernels_bit_identical(stg, solver):
                 env.close()
             for x, y in zip(*outs):
                 assert torch.equal(x, y), (solver, multi, mode)
+            if mode == "budget":
+                noop = int((outs[0][3] == 1).sum())
+                assert 0 < noop < n, noop
 
 
 def test_g12_device_terms_kernel_vs_reference_formulas(stg, golden):
