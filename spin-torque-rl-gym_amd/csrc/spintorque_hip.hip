@@ -34,6 +34,7 @@ struct StateView {
 
 struct CfgView {
     double temperature, max_step, rtol, atol, max_current, max_duration, thr, w_energy;
+    double temp_norm, inv_max_current, inv_max_duration;   // temperature/300, 1/max_current, 1/max_duration (observation)
     double targets[STG_MAX_TARGETS][3];
     uint64_t seed;
     int64_t max_attempts;
@@ -147,8 +148,8 @@ __device__ __forceinline__ void device_reset_draw(uint64_t seed, uint64_t env_id
     const V3 z = ns.draw3_even();
     const uint32_t r = ns.next();
     if (draw_m) {
-        const double n = sqrt(dot(z, z));
-        m = (n < 1e-12) ? V3{0.0, 0.0, 1.0} : V3{z.x / n, z.y / n, z.z / n};
+        const double s2 = dot(z, z), inv = rsqrt_fast(s2);
+        m = (s2 < 1e-24) ? V3{0.0, 0.0, 1.0} : V3{z.x * inv, z.y * inv, z.z * inv};
     }
     if (draw_t) {
         const int idx = (int)__umulhi(r, (uint32_t)c.n_targets);
@@ -169,24 +170,34 @@ __device__ __forceinline__ void write_obs(float* obs, int64_t N, int64_t i, cons
     obs[4 * N + i] = obs_cast(tgt.y);
     obs[5 * N + i] = obs_cast(tgt.z);
     obs[6 * N + i] = obs_cast(r / row[C_RP]);
-    obs[7 * N + i] = obs_cast(c.temperature / 300.0);
+    // (the normalisations by run constants are multiplications by host-computed reciprocals: <= 1 ulp of fp64 away
+    // from the reference's quotients, before the cast to fp32)
+    obs[7 * N + i] = obs_cast(c.temp_norm);
     obs[8 * N + i] = obs_cast((double)(c.max_steps - step) / (double)c.max_steps);
-    obs[9 * N + i] = obs_cast(etot / 1e-12);
-    obs[10 * N + i] = obs_cast(J / c.max_current);
-    obs[11 * N + i] = obs_cast(T / c.max_duration);
+    obs[9 * N + i] = obs_cast(etot * 1e12);
+    obs[10 * N + i] = obs_cast(J * c.inv_max_current);
+    obs[11 * N + i] = obs_cast(T * c.inv_max_duration);
 }
 
-// Adds the sum of v over the executing lanes of the wavefront to *dst with one atomic.  The lane mask is
-// wave-uniform, so the loop is scalar code (v_readlane per executing lane); it runs once per kernel.
-__device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned long long v) {
-    const unsigned long long active = __ballot(1);
-    const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-    unsigned long long sum = 0;
-    for (unsigned long long rem = active; rem; rem &= rem - 1) {
-        const int l = __builtin_ctzll(rem);
-        sum += ((unsigned long long)__builtin_amdgcn_readlane(hi, l) << 32) | __builtin_amdgcn_readlane(lo, l);
+constexpr int COUNTER_STRIPES = 1024;     // copies of the on-device counters (one 64-byte line each)
+constexpr int COUNTER_STRIDE = 8;         // u64 per stripe
+
+// Adds the sums of three per-lane counters over the executing lanes of the wavefront to dst[0], dst[1], dst[3] with one
+// global atomic each.  The lanes accumulate in LDS (ds_add_u64 on one address: the LDS unit serialises the lanes while
+// the wavefront issues nothing); LDS operations of one wavefront complete in order, so no barrier is needed.
+__device__ __forceinline__ void wave_add3(unsigned long long* dst, unsigned long long* lds3, unsigned long long v0,
+                                          unsigned long long v1, unsigned long long v3) {
+    const bool first = (int)__lane_id() == __builtin_ctzll(__ballot(1));
+    if (first) { lds3[0] = 0; lds3[1] = 0; lds3[2] = 0; }
+    atomicAdd(&lds3[0], v0);
+    atomicAdd(&lds3[1], v1);
+    if (__ballot(v3 != 0) != 0ull) atomicAdd(&lds3[2], v3);
+    if (first) {
+        const unsigned long long s0 = lds3[0], s1 = lds3[1], s3 = lds3[2];
+        if (s0) atomicAdd(dst + 0, s0);
+        if (s1) atomicAdd(dst + 1, s1);
+        if (s3) atomicAdd(dst + 3, s3);
     }
-    if ((int)__lane_id() == __builtin_ctzll(active) && sum) atomicAdd(dst, sum);
 }
 
 constexpr int PLAN_DUR = 256;         // 20 ps of pulse duration per bucket at the default 5 ns maximum
@@ -230,6 +241,7 @@ __global__ void __launch_bounds__(PC ? 128 : 64) stg_step_kernel(const StepArgs 
     using NT = typename std::conditional<FIELD, double, float>::type;
     __shared__ NT s_norm[PC ? 2 * SHARED_CHUNK_MAX * 64 : 1];
     __shared__ int s_alive[2], s_go[2];
+    __shared__ unsigned long long s_cnt[3];
     __shared__ uint32_t s_rng[PC ? 64 : 1];
     const int lane = PC ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
     const int64_t lane_slot = stg_slot_block(blockIdx.x, gridDim.x, a.perm != nullptr) * 64 + lane;
@@ -303,8 +315,8 @@ __global__ void __launch_bounds__(PC ? 128 : 64) stg_step_kernel(const StepArgs 
                 energy = (v * v) / r * T;
             }
             if (so.ok) {                                                             // spin_torque_env.py:461-467
-                const double nn = sqrt(dot(so.m, so.m));
-                m = V3{so.m.x / nn, so.m.y / nn, so.m.z / nn};
+                const double inv = rsqrt_fast(dot(so.m, so.m));
+                m = V3{so.m.x * inv, so.m.y * inv, so.m.z * inv};
             }
             etot += energy;
             step += 1;
@@ -350,9 +362,7 @@ __global__ void __launch_bounds__(PC ? 128 : 64) stg_step_kernel(const StepArgs 
     a.s.done[i] = done ? 1 : 0;
     // on-device metrics (the reference's EnvironmentMonitor/solver stats are host-side bookkeeping): one atomic per
     // counter per wavefront
-    wave_add(a.counters + 0, c_steps);
-    wave_add(a.counters + 1, c_sub);
-    wave_add(a.counters + 3, c_noop);
+    wave_add3(a.counters + (size_t)(blockIdx.x % COUNTER_STRIPES) * COUNTER_STRIDE, s_cnt, c_steps, c_sub, c_noop);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -574,6 +584,7 @@ static CfgView cfg_view(const stg_config& c) {
     v.temperature = c.temperature; v.max_step = c.max_step; v.rtol = c.rtol; v.atol = c.atol;
     v.max_current = c.max_current; v.max_duration = c.max_duration; v.thr = c.success_threshold;
     v.w_energy = c.energy_penalty_weight;
+    v.temp_norm = c.temperature / 300.0; v.inv_max_current = 1.0 / c.max_current; v.inv_max_duration = 1.0 / c.max_duration;
     std::memcpy(v.targets, c.targets, sizeof(v.targets));
     v.seed = c.seed; v.max_attempts = c.max_attempts; v.max_steps = c.max_steps; v.n_targets = c.n_targets;
     v.skip_done = c.skip_done;
@@ -618,7 +629,8 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
     const size_t N = (size_t)n_envs;
     const size_t r8 = al(N * 8), r4 = al(N * 4), r1 = al(N);
-    const size_t total = 7 * r8 + 3 * r4 + r1 + al(sizeof(double) * STG_MAX_CLASSES * C_COUNT) + 256;
+    const size_t total = 7 * r8 + 3 * r4 + r1 + al(sizeof(double) * STG_MAX_CLASSES * C_COUNT) +
+                         COUNTER_STRIPES * COUNTER_STRIDE * sizeof(unsigned long long);
     hipError_t e = hipMalloc(&c->slab, total);
     if (e != hipSuccess) { delete c; return fail(STG_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     e = hipMemset(c->slab, 0, total);
@@ -630,7 +642,7 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     c->s.rng = (uint32_t*)p; p += r4;
     c->s.done = (uint8_t*)p; p += r1;
     c->ctab = (double*)p; p += al(sizeof(double) * STG_MAX_CLASSES * C_COUNT);
-    c->counters = (unsigned long long*)p; p += 256;
+    c->counters = (unsigned long long*)p; p += COUNTER_STRIPES * COUNTER_STRIDE * sizeof(unsigned long long);
     c->perm = (uint32_t*)p; p += r4;
     *out = c;
     return STG_OK;
@@ -947,8 +959,16 @@ int stg_get_counters(stg_ctx* ctx, uint64_t* out, int32_t reset) {
     if (!ctx || !out) return fail(STG_E_INVALID, "ctx/out is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, ctx->counters, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(hipMemset(ctx->counters, 0, 4 * sizeof(uint64_t)));
+    // the kernels add into COUNTER_STRIPES copies (a workgroup picks one by its index: thousands of wavefronts on one
+    // address would serialise in the memory-side atomic unit); the stripes are summed here
+    static_assert(sizeof(uint64_t) == sizeof(unsigned long long), "counter width");
+    uint64_t h[COUNTER_STRIPES * COUNTER_STRIDE];
+    HIP_TRY(hipMemcpy(h, ctx->counters, sizeof(h), hipMemcpyDeviceToHost));
+    for (int j = 0; j < 4; ++j) {
+        out[j] = 0;
+        for (int st = 0; st < COUNTER_STRIPES; ++st) out[j] += h[st * COUNTER_STRIDE + j];
+    }
+    if (reset) HIP_TRY(hipMemset(ctx->counters, 0, sizeof(h)));
     return STG_OK;
 }
 

@@ -108,6 +108,22 @@ __device__ __forceinline__ double inv_tenth_root(double e2) {
     return __builtin_fma(y * e, __builtin_fma(0.055, e, 0.1), y);     // y (1 + e/10 + 11 e^2/200)
 }
 
+// x^(1/5) for finite x > 0 (any exponent): r = x^(-1/5) from an fp32 transcendental seed on the mantissa plus one
+// third-order Newton step on r^-5 = x (~1 ulp), then x * r^4.  Stands in for the libm pow of SciPy's
+// select_initial_step (common.py:128); the result only seeds the first step size.
+__device__ __forceinline__ double fifth_root(double x) {
+    int e;
+    const double mant = frexp(x, &e);                                     // x = mant 2^e, mant in [0.5, 1)
+    const double t = -0.2 * ((double)e + (double)__builtin_amdgcn_logf((float)mant));   // log2(x^(-1/5))
+    const double ti = rint(t);
+    double r = ldexp((double)__builtin_amdgcn_exp2f((float)(t - ti)), (int)ti);
+    const double r2 = r * r, r4 = r2 * r2;
+    const double err = __builtin_fma(-x, r4 * r, 1.0);                    // 1 - x r^5
+    r = __builtin_fma(r * err, __builtin_fma(0.12, err, 0.2), r);         // r (1 + e/5 + 3 e^2/25)
+    const double q2 = r * r;
+    return x * (q2 * q2);
+}
+
 // cross/dot spell their FMAs out (contraction of a*b - c*d is otherwise the backend's choice and can change with the
 // surrounding code, i.e. between two instantiations of the same source)
 __device__ __forceinline__ V3 cross(const V3& a, const V3& b) {
@@ -606,15 +622,17 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
     V3 f = fun(t, y, true);
     double h_abs;
     {   // select_initial_step (common.py:68-134), order = error_estimator_order = 4
+        // (quotients by reciprocal-multiply, ~1 ulp: these norms only seed the first step size)
         const V3 sc{atol + fabs(y.x) * rtol, atol + fabs(y.y) * rtol, atol + fabs(y.z) * rtol};
-        const double d0 = rms3(V3{y.x / sc.x, y.y / sc.y, y.z / sc.z});
-        const double d1 = rms3(V3{f.x / sc.x, f.y / sc.y, f.z / sc.z});
-        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        const V3 isc{rcp_fast(sc.x), rcp_fast(sc.y), rcp_fast(sc.z)};
+        const double d0 = rms3(V3{y.x * isc.x, y.y * isc.y, y.z * isc.z});
+        const double d1 = rms3(V3{f.x * isc.x, f.y * isc.y, f.z * isc.z});
+        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : (0.01 * d0) * rcp_fast(d1);
         h0 = fmin(h0, T);
         const V3 y1{y.x + h0 * f.x, y.y + h0 * f.y, y.z + h0 * f.z};
         const V3 f1 = fun(add_x(t, h0), y1, false);
-        const double d2 = rms3(V3{(f1.x - f.x) / sc.x, (f1.y - f.y) / sc.y, (f1.z - f.z) / sc.z}) / h0;
-        const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : pow(0.01 / fmax(d1, d2), 0.2);
+        const double d2 = rms3(V3{(f1.x - f.x) * isc.x, (f1.y - f.y) * isc.y, (f1.z - f.z) * isc.z}) * rcp_fast(h0);
+        const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : fifth_root(0.01 * rcp_fast(fmax(d1, d2)));
         h_abs = fmin(fmin(100.0 * h0, h1), fmin(T, max_step));
     }
     // SciPy nests "while not finished: step()" around "while not step_accepted: attempt" (ivp.py:654-661, base.py:175-206,
@@ -711,12 +729,12 @@ __device__ __forceinline__ double resistance(const V3& m_in, int dev_type, doubl
                                              const V3& ref, double r_series) {
 #pragma clang fp contract(off)
     if (dev_type == 0) {
-        const double mn = sqrt(dot(m_in, m_in));               // base_device.py:112-116
-        const V3 m{m_in.x / mn, m_in.y / mn, m_in.z / mn};
-        const double r = r_p * (1.0 + tmr * (1.0 - dot(m, ref)) / 2.0);
+        const double inv = rsqrt_fast(dot(m_in, m_in));        // validate_magnetization, base_device.py:112-116
+        const V3 m{m_in.x * inv, m_in.y * inv, m_in.z * inv};
+        const double r = r_p * (1.0 + tmr * (1.0 - dot(m, ref)) * 0.5);
         return fmax(r, r_p * 0.5);
     }
-    double r = r_p + (r_ap - r_p) * (1.0 - dot(m_in, ref)) / 2.0;
+    double r = r_p + (r_ap - r_p) * (1.0 - dot(m_in, ref)) * 0.5;
     if (dev_type == 1) r = r + r_series;
     return fmax(r, 1.0);
 }
