@@ -135,7 +135,11 @@ def run_config(n_local, solver, thermal, steps, warmup, rank, world, device_inde
             backend.step(acts[warmup + k], autoreset=True)          # the step kernel, on torch's current stream
             ends[k].record()
             if world > 1:
-                env._gather(unpack=False)                            # the single collective of a step
+                if k:
+                    env.gather_end(unpack=False)                     # step k-1's gather ran under step k's kernel
+                env.gather_begin()                                   # the single collective of a step, on its own stream
+        if world > 1:
+            env.gather_end(unpack=False)
         fin.record()
         torch.cuda.synchronize(dev)
         if world > 1:
@@ -258,7 +262,8 @@ def run_short_pulse_config(n, steps, device_index, K=1):
 
 def _sharded_step(env, a):
     env.local.backend.step(a, autoreset=True)
-    env._gather(unpack=False)
+    env.gather_begin()
+    env.gather_end(unpack=False)
 
 
 def pmc_traffic(solver, thermal, n_local, sorted_schedule):

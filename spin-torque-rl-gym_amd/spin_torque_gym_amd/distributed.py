@@ -8,6 +8,8 @@ of ranks).  The only communication is what an RL learner needs: the step's (obs,
 CPU tests run the same code over gloo).  At 131 072 envs per GPU that is 7.1 MB per rank per step.
 Actions go the other way: every rank slices its shard out of the global action tensor (a learner that is itself
 data-parallel over the same ranks would pass local actions and skip the gather: ``gather=False``).
+`gather_begin` / `gather_end` split the collective from the step so that it overlaps the next step's kernel on a
+separate HIP stream (a pipelined actor that acts on observations one step old, or a recorder).
 """
 from typing import Optional
 
@@ -47,7 +49,19 @@ class ShardedSpinTorqueVecEnv:
         self.local = SpinTorqueVecEnv(self.n_local, class_index=class_index, device_index=device_index, env_id0=self.lo,
                                       **env_kwargs)
         dev = self.local.backend.packed.device
-        self._gathered = torch.zeros(self.world * PACKED_BYTES_PER_ENV * self.n_local, dtype=torch.uint8, device=dev)
+        nbytes = PACKED_BYTES_PER_ENV * self.n_local
+        self._gathered = torch.zeros(self.world * nbytes, dtype=torch.uint8, device=dev)
+        # pipelined gather (gather_begin / gather_end): the step's packed outputs are copied to a staging slot and the
+        # all-gather runs on its own stream while the next step's kernel runs; two slots, so a slot is reused only
+        # after the gather that read it has finished
+        self._overlap = dev.type == "cuda" and dist.get_backend(group) != "gloo"
+        self._send = [torch.zeros(nbytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self._recv = [self._gathered, torch.zeros_like(self._gathered)]
+        self._slot = 0
+        self._pending = None
+        if self._overlap:
+            self._comm_stream = torch.cuda.Stream(device=dev)
+            self._done = [None, None]
 
     def _gather(self, unpack: bool = True):
         """The single collective of a step.  unpack=False returns the raw [world * 54 * n_local] byte buffer (rank-major;
@@ -62,14 +76,54 @@ class ShardedSpinTorqueVecEnv:
             dist.all_gather_into_tensor(self._gathered, packed, group=self.group)
         if not unpack:
             return self._gathered
+        return self._unpack_all(self._gathered)
+
+    def _unpack_all(self, buf):
         n = self.n_local
-        parts = [unpack_step_buffer(self._gathered[r * PACKED_BYTES_PER_ENV * n:(r + 1) * PACKED_BYTES_PER_ENV * n], n)
+        parts = [unpack_step_buffer(buf[r * PACKED_BYTES_PER_ENV * n:(r + 1) * PACKED_BYTES_PER_ENV * n], n)
                  for r in range(self.world)]
         obs = torch.cat([p[0] for p in parts], dim=1)       # [12, N_global]
         reward = torch.cat([p[1] for p in parts])
         term = torch.cat([p[2] for p in parts])
         trunc = torch.cat([p[3] for p in parts])
         return obs.t(), reward, term.bool(), trunc.bool()
+
+    def gather_begin(self):
+        """Starts the all-gather of the step just enqueued and returns at once: the collective runs on a side stream
+        (RCCL over xGMI) concurrently with whatever the caller enqueues next -- normally the next step's kernel.  Pair
+        with `gather_end`.  One gather may be in flight per slot (two slots)."""
+        k = self._slot
+        self._slot ^= 1
+        packed = self.local.backend.packed
+        if not self._overlap:
+            self._pending = ("sync", self._gather(unpack=False))
+            return
+        cur = torch.cuda.current_stream(packed.device)
+        if self._done[k] is not None:
+            cur.wait_event(self._done[k])                    # the gather that last read this slot has finished
+        self._send[k].copy_(packed, non_blocking=True)       # 54 B/env device-to-device, on the compute stream
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with torch.cuda.stream(self._comm_stream):
+            self._comm_stream.wait_event(ready)
+            dist.all_gather_into_tensor(self._recv[k], self._send[k], group=self.group)
+            done = torch.cuda.Event()
+            done.record(self._comm_stream)
+        self._done[k] = done
+        self._pending = ("async", k)
+
+    def gather_end(self, unpack: bool = True):
+        """Makes the current stream wait for the gather started last and returns its result (see `_gather`)."""
+        if self._pending is None:
+            raise RuntimeError("gather_end without gather_begin")
+        kind, v = self._pending
+        self._pending = None
+        if kind == "sync":
+            buf = v
+        else:
+            torch.cuda.current_stream(self._recv[v].device).wait_event(self._done[v])
+            buf = self._recv[v]
+        return self._unpack_all(buf) if unpack else buf
 
     def reset(self, seed: Optional[int] = None, options=None, gather: bool = True):
         options = dict(options or {})

@@ -42,6 +42,12 @@ def _worker(rank, world, port, n, steps, q):
         obs, r, te, tr, _ = env.step(torch.from_numpy(acts[k]))
         rec.append((obs.clone(), r.clone(), te.clone(), tr.clone()))
     assert (env.lo, env.hi) == (rank * n // world, (rank + 1) * n // world)
+    # split form of the collective (gather_begin / gather_end; overlaps the next kernel on a GPU, synchronous over gloo)
+    env.step(torch.from_numpy(acts[0]), gather=False)
+    env.gather_begin()
+    g1 = env.gather_end()
+    g2 = env._gather()
+    assert all(torch.equal(a, b) for a, b in zip(g1, g2))
     if rank == 0:
         q.put(rec)
     dist.barrier()

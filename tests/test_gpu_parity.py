@@ -10,6 +10,8 @@ division/sqrt/pow, so they differ from NumPy by rounding only.
   reward (fp64) .......... <= 1e-10 relative
   integer/boolean outputs  exact (sub-step counts, success flags, terminated/truncated, status)
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -825,3 +827,34 @@ def test_integration_md_ctypes_stub_runs(stg):
     torch.cuda.synchronize()
     obs = ns["obs"]
     assert torch.isfinite(obs).all() and torch.all(torch.abs(torch.linalg.norm(obs[:3].double(), dim=0) - 1) < 1e-6)
+
+
+def test_pipelined_gather_overlaps_and_matches_sync(stg):
+    """ShardedSpinTorqueVecEnv.gather_begin/gather_end (the all-gather on its own stream under the next step's kernel)
+    against the synchronous gather, through RCCL with a world of one rank (the 8-GPU run is the driver's)."""
+    import socket
+    import torch.distributed as dist
+    from spin_torque_gym_amd.distributed import ShardedSpinTorqueVecEnv
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n, steps = 8192, 4
+        rng = np.random.default_rng(3)
+        acts = [torch.from_numpy(_uniform_actions(2e6, 1e-10, 3e-10)(rng, n, k)) for k in range(steps)]
+        kw = dict(device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=True, seed=9, autoreset=True)
+        e1 = ShardedSpinTorqueVecEnv(n, **kw); e1.reset(seed=2, gather=False)
+        e2 = ShardedSpinTorqueVecEnv(n, **kw); e2.reset(seed=2, gather=False)
+        sync = [tuple(t.clone() for t in e1.step(a)[:4]) for a in acts]
+        piped = []
+        for k, a in enumerate(acts):
+            e2.step(a, gather=False)
+            if k:
+                piped.append(tuple(t.clone() for t in e2.gather_end()))     # step k-1, gathered under step k's kernel
+            e2.gather_begin()
+        piped.append(tuple(t.clone() for t in e2.gather_end()))
+        for a, b in zip(sync, piped):
+            assert all(torch.equal(x, y) for x, y in zip(a, b))
+        e1.close(); e2.close()
+    finally:
+        dist.destroy_process_group()
