@@ -592,16 +592,18 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
     constexpr double A61 = 9017.0 / 3168, A62 = -355.0 / 33, A63 = 46732.0 / 5247, A64 = 49.0 / 176, A65 = -5103.0 / 18656;
     constexpr double B1 = 35.0 / 384, B3 = 500.0 / 1113, B4 = 125.0 / 192, B5 = -2187.0 / 6784, B6 = 11.0 / 84;
     constexpr double E1 = -71.0 / 57600, E3 = 71.0 / 16695, E4 = -71.0 / 1920, E5 = 17253.0 / 339200, E6 = -22.0 / 525, E7 = 1.0 / 40;
-    constexpr double C2 = 1.0 / 5, C3 = 3.0 / 10, C4 = 4.0 / 5, C5 = 8.0 / 9;
+    // (stage nodes C = 1/5, 3/10, 4/5, 8/9, 1, 1: the RHS is autonomous but for the pulse gate, see `fun`)
 
     SolveOut o{m0, 0, 0, 0, false};
     const bool useJ = !(fabs(J) < 1e-12);                                   // llgs_solver.py:222
     const double bJ = useJ ? beta * J : 0.0, bpJ = useJ ? betap * J : 0.0;
     const V3 zero{0.0, 0.0, 0.0};
     if (THERMAL) ns.begin(rk);
-    // RHS call with the pulse gate of spin_torque_env.py:442-443; EVEN selects the normal-stream phase (calls alternate)
-    auto fun = [&](double t, const V3& y, bool even) -> V3 {
-        const bool on = t <= T;
+    // RHS call; EVEN selects the normal-stream phase (calls alternate).  The pulse gate of spin_torque_env.py:442-443
+    // (J while t <= T) can only close for stage times of the form fl(t + h) on the step that is clamped to end at T:
+    // every other stage time is fl(t + fl(c h)) with c <= 8/9, hence <= t_new <= T by monotonic rounding, and an
+    // unclamped fl(t + h) is within an ulp of t_new < T.  So only k6 / f_new of an attempt test the gate (`on`).
+    auto fun = [&](const V3& y, bool even, bool on) -> V3 {
         V3 ht = zero;
         if (THERMAL) ht = NSRC::kScaled ? ns.draw(even) : scale3(k.ghs, ns.draw(even));
         return llgs_rhs<THERMAL, AXIS_Z>(y, k, on ? bJ : 0.0, on ? bpJ : 0.0, ht);
@@ -619,7 +621,7 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
         ++npts;
     };
     if (RECORD) emit(); else ++npts;
-    V3 f = fun(t, y, true);
+    V3 f = fun(y, true, true);                             // t = 0 <= T
     double h_abs;
     {   // select_initial_step (common.py:68-134), order = error_estimator_order = 4
         // (quotients by reciprocal-multiply, ~1 ulp: these norms only seed the first step size)
@@ -630,7 +632,7 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
         double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : (0.01 * d0) * rcp_fast(d1);
         h0 = fmin(h0, T);
         const V3 y1{y.x + h0 * f.x, y.y + h0 * f.y, y.z + h0 * f.z};
-        const V3 f1 = fun(add_x(t, h0), y1, false);
+        const V3 f1 = fun(y1, false, true);                // t + h0 = h0 <= T (h0 = min(h0, T))
         const double d2 = rms3(V3{(f1.x - f.x) * isc.x, (f1.y - f.y) * isc.y, (f1.z - f.z) * isc.z}) * rcp_fast(h0);
         const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : fifth_root(0.01 * rcp_fast(fmax(d1, d2)));
         h_abs = fmin(fmin(100.0 * h0, h1), fmin(T, max_step));
@@ -663,27 +665,24 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
         if (t_new - T > 0.0) t_new = T;
         const double h = sub_x(t_new, t);
         h_abs = fabs(h);
-        // rk_step (rk.py:14-70); stage times must not be contracted into FMAs (they gate the pulse)
+        // rk_step (rk.py:14-70); the one stage time that can pass T is formed without contraction
+        const bool on_end = add_x(t, h) <= T;
         const V3 k1 = f;
-        const V3 k2 = fun(add_x(t, mul_x(C2, h)), V3{y.x + (k1.x * A21) * h, y.y + (k1.y * A21) * h, y.z + (k1.z * A21) * h}, true);
-        const V3 k3 = fun(add_x(t, mul_x(C3, h)),
-                          V3{y.x + (k1.x * A31 + k2.x * A32) * h, y.y + (k1.y * A31 + k2.y * A32) * h,
-                             y.z + (k1.z * A31 + k2.z * A32) * h}, false);
-        const V3 k4 = fun(add_x(t, mul_x(C4, h)),
-                          V3{y.x + (k1.x * A41 + k2.x * A42 + k3.x * A43) * h, y.y + (k1.y * A41 + k2.y * A42 + k3.y * A43) * h,
-                             y.z + (k1.z * A41 + k2.z * A42 + k3.z * A43) * h}, true);
-        const V3 k5 = fun(add_x(t, mul_x(C5, h)),
-                          V3{y.x + (k1.x * A51 + k2.x * A52 + k3.x * A53 + k4.x * A54) * h,
+        const V3 k2 = fun(V3{y.x + (k1.x * A21) * h, y.y + (k1.y * A21) * h, y.z + (k1.z * A21) * h}, true, true);
+        const V3 k3 = fun(V3{y.x + (k1.x * A31 + k2.x * A32) * h, y.y + (k1.y * A31 + k2.y * A32) * h,
+                             y.z + (k1.z * A31 + k2.z * A32) * h}, false, true);
+        const V3 k4 = fun(V3{y.x + (k1.x * A41 + k2.x * A42 + k3.x * A43) * h, y.y + (k1.y * A41 + k2.y * A42 + k3.y * A43) * h,
+                             y.z + (k1.z * A41 + k2.z * A42 + k3.z * A43) * h}, true, true);
+        const V3 k5 = fun(V3{y.x + (k1.x * A51 + k2.x * A52 + k3.x * A53 + k4.x * A54) * h,
                              y.y + (k1.y * A51 + k2.y * A52 + k3.y * A53 + k4.y * A54) * h,
-                             y.z + (k1.z * A51 + k2.z * A52 + k3.z * A53 + k4.z * A54) * h}, false);
-        const V3 k6 = fun(add_x(t, h),
-                          V3{y.x + (k1.x * A61 + k2.x * A62 + k3.x * A63 + k4.x * A64 + k5.x * A65) * h,
+                             y.z + (k1.z * A51 + k2.z * A52 + k3.z * A53 + k4.z * A54) * h}, false, true);
+        const V3 k6 = fun(V3{y.x + (k1.x * A61 + k2.x * A62 + k3.x * A63 + k4.x * A64 + k5.x * A65) * h,
                              y.y + (k1.y * A61 + k2.y * A62 + k3.y * A63 + k4.y * A64 + k5.y * A65) * h,
-                             y.z + (k1.z * A61 + k2.z * A62 + k3.z * A63 + k4.z * A64 + k5.z * A65) * h}, true);
+                             y.z + (k1.z * A61 + k2.z * A62 + k3.z * A63 + k4.z * A64 + k5.z * A65) * h}, true, on_end);
         const V3 y_new{y.x + h * (k1.x * B1 + k3.x * B3 + k4.x * B4 + k5.x * B5 + k6.x * B6),
                        y.y + h * (k1.y * B1 + k3.y * B3 + k4.y * B4 + k5.y * B5 + k6.y * B6),
                        y.z + h * (k1.z * B1 + k3.z * B3 + k4.z * B4 + k5.z * B5 + k6.z * B6)};
-        const V3 f_new = fun(add_x(t, h), y_new, false);
+        const V3 f_new = fun(y_new, false, on_end);
         const V3 ev{(k1.x * E1 + k3.x * E3 + k4.x * E4 + k5.x * E5 + k6.x * E6 + f_new.x * E7) * h,
                     (k1.y * E1 + k3.y * E3 + k4.y * E4 + k5.y * E5 + k6.y * E6 + f_new.y * E7) * h,
                     (k1.z * E1 + k3.z * E3 + k4.z * E4 + k5.z * E5 + k6.z * E6 + f_new.z * E7) * h};
