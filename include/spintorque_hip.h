@@ -99,6 +99,15 @@ typedef struct {
                                        on the device before each step so that the lanes of a wavefront have equal trip
                                        counts, -1 = identity.  Results are unaffected: an env's arithmetic does not depend
                                        on the lane that runs it. */
+    int32_t noise_model;            /* thermal field of the fixed-step solvers: 0 (default) = white, three fresh normals
+                                       per RHS call (what the reference solvers do, simple_solver.py:378-388);
+                                       1 = Ornstein-Uhlenbeck, the reference's ThermalFluctuations model
+                                       (physics/thermal_model.py:113-137): once per sub-step
+                                       x <- d x + sqrt(1 - d^2) xi, d = exp(-dt / noise_corr_time), field = strength * x
+                                       for all stages of the sub-step, x = 0 at the start of every pulse.
+                                       Not available with STG_SOLVER_RK45 (no fixed dt). */
+    int32_t reserved;
+    double noise_corr_time;         /* correlation_time of ThermalFluctuations (default 1e-12 s); used when noise_model = 1 */
 } stg_config;
 
 /* one reference-style device_params dict, flattened with the defaults the reference's .get() calls use

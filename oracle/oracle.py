@@ -17,7 +17,7 @@ __all__ = ["Params", "Config", "EnvState", "StepOut", "lib", "build", "make_para
            "simple_solve", "llgs_solve", "resistance", "thermal_strength", "env_step", "env_step_batch",
            "thermal_normals", "parse_action", "simple_dmdt", "llgs_rhs", "DEV_TYPES", "sot_torque", "vcma_keff",
            "ArrayConfig", "make_array_config", "array_coupling", "ArrayEnvState", "array_step", "array_observation",
-           "device_field"]
+           "device_field", "ou_update"]
 
 DEV_TYPES = {"stt_mram": 0, "sot_mram": 1, "vcma_mram": 2}
 
@@ -43,7 +43,8 @@ class Config(C.Structure):
                 ("gamma", C.c_double), ("max_step", C.c_double), ("rtol", C.c_double), ("atol", C.c_double),
                 ("max_steps", C.c_int32), ("max_current", C.c_double), ("max_duration", C.c_double),
                 ("success_threshold", C.c_double), ("energy_penalty_weight", C.c_double),
-                ("seed", C.c_uint64), ("max_attempts", C.c_int64), ("torque_model", C.c_int32)]
+                ("seed", C.c_uint64), ("max_attempts", C.c_int64), ("torque_model", C.c_int32),
+                ("noise_model", C.c_int32), ("noise_corr_time", C.c_double)]
 
 
 class EnvState(C.Structure):
@@ -117,6 +118,8 @@ def lib():
         L.stgo_array_observation.argtypes = [C.POINTER(ArrayConfig), dp, dp, C.c_double, C.c_int32, C.POINTER(C.c_float)]
         L.stgo_device_field.restype = None
         L.stgo_device_field.argtypes = [dp, C.POINTER(Params), dp]
+        L.stgo_ou_update.restype = None
+        L.stgo_ou_update.argtypes = [dp, dp, C.c_double, C.c_double]
         L.stgo_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -207,7 +210,8 @@ def make_params(device_params, device_type="stt_mram"):
 
 def make_config(solver="rk4", thermal=False, temperature=300.0, gamma=2.21e5, max_step=1e-12, rtol=1e-6,
                 atol=1e-9, max_steps=100, max_current=2e6, max_duration=5e-9, success_threshold=0.9,
-                energy_penalty_weight=0.1, seed=0, max_attempts=10_000_000, torque_model=0):
+                energy_penalty_weight=0.1, seed=0, max_attempts=10_000_000, torque_model=0, noise_model=0,
+                noise_corr_time=1e-12):
     c = Config()
     c.solver = {"rk4": 0, "euler": 1, "rk45": 2}[solver]
     c.thermal = int(bool(thermal))
@@ -216,6 +220,7 @@ def make_config(solver="rk4", thermal=False, temperature=300.0, gamma=2.21e5, ma
     c.success_threshold, c.energy_penalty_weight = success_threshold, energy_penalty_weight
     c.seed, c.max_attempts = seed, max_attempts
     c.torque_model = int(torque_model)
+    c.noise_model, c.noise_corr_time = int(noise_model), float(noise_corr_time)
     return c
 
 
@@ -391,3 +396,11 @@ def env_step_batch(states, actions, params, cls, c, env_id0=0, n_threads=0):
     lib().stgo_env_step_batch(n, states, a.ctypes.data_as(C.POINTER(C.c_float)), params, cp, C.byref(c),
                               env_id0, outs, n_threads)
     return outs
+
+
+def ou_update(x, xi, dt, corr_time):
+    """ThermalFluctuations._generate_correlated_noise state update (thermal_model.py:113-137); returns the new x."""
+    x = np.ascontiguousarray(x, dtype=np.float64).copy()
+    xi = np.ascontiguousarray(xi, dtype=np.float64)
+    lib().stgo_ou_update(_dp(x), _dp(xi), float(dt), float(corr_time))
+    return x

@@ -220,6 +220,13 @@ static int validation_rejects(const double m[3]) {
 /* ------------------------------------------------------------------------------------------------
  * A3 + A4 + A5  RobustLLGSSolver.solve -> SimpleLLGSSolver.solve (rk4 / euler)
  * ------------------------------------------------------------------------------------------------ */
+/* physics/thermal_model.py:113-137 */
+void stgo_ou_update(double x[3], const double xi[3], double dt, double corr_time) {
+    const double decay = corr_time > 0 ? exp(-dt / corr_time) : 0.0;       /* :120-123 */
+    const double w = sqrt(1 - decay * decay);                              /* :129-132 */
+    for (int j = 0; j < 3; ++j) x[j] = decay * x[j] + w * xi[j];
+}
+
 int stgo_simple_solve(const double m0[3], double T, const stgo_params* p, const stgo_config* c,
                       double J, uint64_t env_id, uint32_t env_step,
                       double m_final[3], int32_t* n_steps, int32_t* first_zero_row, int32_t* n_reset,
@@ -252,10 +259,19 @@ int stgo_simple_solve(const double m0[3], double T, const stgo_params* p, const 
     if (thermal) ns_init(&g, c->seed, env_id, env_step, 0u);
     if (traj && traj_cap_rows > 0) { traj[0] = m[0]; traj[1] = m[1]; traj[2] = m[2]; }
 
+    /* noise_model 1: ThermalFluctuations' correlated field, one update per sub-step (x = 0 when the pulse starts),
+     * held for all stages of the sub-step */
+    const int ou = thermal && c->noise_model == 1;
+    double oux[3] = {0.0, 0.0, 0.0};
     for (int i = 0; i < n; ++i) {
         double t = (double)i * dt + 0.0;           /* np.linspace(0, T, n+1)[i] = i*step + start */
         double k[4][3], y[3], hth[3], z[3];
         const int nstage = (c->solver == 1) ? 1 : 4;
+        if (ou) {
+            ns_draw3(&g, z);
+            stgo_ou_update(oux, z, dt, c->noise_corr_time);
+            hth[0] = hs * oux[0]; hth[1] = hs * oux[1]; hth[2] = hs * oux[2];
+        }
         for (int s = 0; s < nstage; ++s) {
             double ts;
             if (s == 0) { ts = t; y[0] = m[0]; y[1] = m[1]; y[2] = m[2]; }
@@ -263,7 +279,7 @@ int stgo_simple_solve(const double m0[3], double T, const stgo_params* p, const 
             else { ts = t + dt; for (int j = 0; j < 3; ++j) y[j] = m[j] + k[2][j]; }
             /* spin_torque_env.py:442-443  current_func(t) = J if t <= T else 0 */
             double Jt = (ts <= T) ? J : 0.0;
-            if (thermal) {
+            if (thermal && !ou) {
                 ns_draw3(&g, z);
                 hth[0] = hs * z[0]; hth[1] = hs * z[1]; hth[2] = hs * z[2];
             }

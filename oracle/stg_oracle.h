@@ -64,7 +64,14 @@ typedef struct {
     uint64_t seed;                  /* thermal-field Philox key */
     int64_t max_attempts;           /* RK45 attempt budget per solve (guard; reference has none) */
     int32_t torque_model;           /* 0 reference RHS; 1 device-physics torque model (include/spintorque_hip.h) */
+    int32_t noise_model;            /* fixed-step solvers: 0 white field per RHS call (simple_solver.py:378-388);
+                                       1 Ornstein-Uhlenbeck field per sub-step (physics/thermal_model.py:113-137) */
+    double noise_corr_time;         /* ThermalFluctuations.correlation_time */
 } stgo_config;
+
+/* ThermalFluctuations._generate_correlated_noise (physics/thermal_model.py:113-137): one update of the unit-variance
+ * Ornstein-Uhlenbeck state x with the white sample xi; the field is strength * x */
+void stgo_ou_update(double x[3], const double xi[3], double dt, double corr_time);
 
 /* per-env mutable state (envs/spin_torque_env.py:133-139) */
 typedef struct {

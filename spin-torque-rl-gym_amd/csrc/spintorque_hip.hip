@@ -35,6 +35,7 @@ struct StateView {
 struct CfgView {
     double temperature, max_step, rtol, atol, max_current, max_duration, thr, w_energy;
     double temp_norm, inv_max_current, inv_max_duration;   // temperature/300, 1/max_current, 1/max_duration (observation)
+    double inv_tau;               // 1/noise_corr_time when the Ornstein-Uhlenbeck field is selected, else 0 (white field)
     double targets[STG_MAX_TARGETS][3];
     uint64_t seed;
     int64_t max_attempts;
@@ -135,7 +136,7 @@ __device__ __forceinline__ SolveOut run_solver(const V3& m, double J, double T, 
         }
     }
     return simple_solve<SOLVER == STG_SOLVER_EULER ? 1 : 0, THERMAL, RECORD, AXIS_Z, DEVPHYS>(
-        m, J, T, k, pol, row[C_MSV], row[C_VALID] != 0.0, c.temperature, c.max_step, rk, rec, dv, ns);
+        m, J, T, k, pol, row[C_MSV], row[C_VALID] != 0.0, c.temperature, c.max_step, rk, rec, dv, ns, c.inv_tau);
 }
 
 // SpinTorqueEnv.reset draws (spin_torque_env.py:286-299) from the device generator: normal(0,1,3) normalised and a
@@ -256,8 +257,10 @@ __global__ void __launch_bounds__(PC ? 128 : 64) stg_step_kernel(const StepArgs 
 
     if (PC && threadIdx.x >= 64) {
         // producer wavefront: per env-step, wait for the consumer's stream position, then stay one chunk ahead
-        constexpr int n_first = SOLVER == STG_SOLVER_RK45 ? 6 : (SOLVER == STG_SOLVER_RK4 ? 12 : 3);
-        constexpr int n_chunk = SOLVER == STG_SOLVER_RK45 ? 18 : n_first;
+        // normals per chunk: RK45 6 (initial step) then 18 per attempt; RK4 12 per sub-step; Euler and the
+        // Ornstein-Uhlenbeck field 3 per sub-step
+        const int n_first = SOLVER == STG_SOLVER_RK45 ? 6 : ((SOLVER == STG_SOLVER_RK4 && !(a.c.inv_tau > 0.0)) ? 12 : 3);
+        const int n_chunk = SOLVER == STG_SOLVER_RK45 ? 18 : n_first;
         const double ghs = FIELD ? load_llgs(row).ghs : 0.0;
         for (int k = 0; k < a.K; ++k) {
             __syncthreads();                                       // H1: s_rng / s_go[k & 1] published
@@ -584,6 +587,7 @@ static CfgView cfg_view(const stg_config& c) {
     v.temperature = c.temperature; v.max_step = c.max_step; v.rtol = c.rtol; v.atol = c.atol;
     v.max_current = c.max_current; v.max_duration = c.max_duration; v.thr = c.success_threshold;
     v.w_energy = c.energy_penalty_weight;
+    v.inv_tau = (c.noise_model == 1 && c.solver != STG_SOLVER_RK45) ? 1.0 / c.noise_corr_time : 0.0;
     v.temp_norm = c.temperature / 300.0; v.inv_max_current = 1.0 / c.max_current; v.inv_max_duration = 1.0 / c.max_duration;
     std::memcpy(v.targets, c.targets, sizeof(v.targets));
     v.seed = c.seed; v.max_attempts = c.max_attempts; v.max_steps = c.max_steps; v.n_targets = c.n_targets;
@@ -599,6 +603,9 @@ static int check_cfg(const stg_config* c) {
     if (c->max_steps < 1) return fail(STG_E_INVALID, "cfg.max_steps must be >= 1");
     if (!(c->max_current > 0) || !(c->max_duration > 0)) return fail(STG_E_INVALID, "cfg.max_current/max_duration must be positive");
     if (c->solver == STG_SOLVER_RK45 && (!(c->rtol > 0) || !(c->atol >= 0))) return fail(STG_E_INVALID, "cfg.rtol/atol invalid");
+    if (c->noise_model != 0 && c->noise_model != 1) return fail(STG_E_INVALID, "cfg.noise_model must be 0 (white) or 1 (Ornstein-Uhlenbeck)");
+    if (c->noise_model == 1 && c->solver == STG_SOLVER_RK45) return fail(STG_E_INVALID, "cfg.noise_model = 1 needs a fixed-step solver (RK4 or Euler)");
+    if (c->noise_model == 1 && !(c->noise_corr_time > 0)) return fail(STG_E_INVALID, "cfg.noise_corr_time must be positive");
     if (c->solver == STG_SOLVER_RK45 && c->max_attempts < 1) return fail(STG_E_INVALID, "cfg.max_attempts must be >= 1");
     if (c->torque_model < 0 || c->torque_model > 1) return fail(STG_E_INVALID, "cfg.torque_model must be 0 or 1");
     if (c->torque_model == 1 && c->solver == STG_SOLVER_RK45)

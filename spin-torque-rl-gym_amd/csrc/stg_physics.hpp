@@ -452,7 +452,8 @@ struct Recorder {
 template <int METHOD, bool THERMAL, bool RECORD, bool AXIS_Z, bool DEVPHYS, class NSRC>
 __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double T, const SimpleK& k, double pol,
                                                  double msv, bool class_valid, double temperature, double max_step,
-                                                 const RngKey& rk, const Recorder& rec, const DevTorque& dv, NSRC& ns) {
+                                                 const RngKey& rk, const Recorder& rec, const DevTorque& dv, NSRC& ns,
+                                                 double inv_tau) {
 #pragma clang fp contract(off)
     SolveOut o{m0, 0, 0, 0, false};
     // robust_solver.py:152-190 (_validate_inputs); any failure ends in the fallback result (:140-150)
@@ -485,6 +486,16 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
     bool fail = false;
     const V3 zero{0.0, 0.0, 0.0};
     if (THERMAL) ns.begin(rk);
+    // Ornstein-Uhlenbeck field (ThermalFluctuations._generate_correlated_noise, thermal_model.py:113-137), selected by a
+    // wave-uniform inv_tau > 0: one update per sub-step, x <- d x + sqrt(1 - d^2) xi with d = exp(-dt/tau), and the same
+    // x for every stage of the sub-step; the stream hands out three normals per sub-step, alternating phase like Euler's
+    const bool ou = THERMAL && inv_tau > 0.0;
+    double ou_d = 0.0, ou_c = 1.0;
+    V3 ou_x = zero;
+    if (ou) {
+        ou_d = exp(-dt * inv_tau);
+        ou_c = sqrt(1.0 - ou_d * ou_d);
+    }
     if (RECORD) rec.put(0, 0.0, m, 0.0);
     // per-lane trip count n; with SharedNormals the loop is wave-uniform (lanes past their n idle inside the body)
     for (int i = 0; NSRC::kShared || i < n; ++i) {
@@ -496,11 +507,21 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
         if (METHOD == 1) {
             V3 z0 = zero;
             if (THERMAL) z0 = ns.draw((i & 1) == 0);
+            if (ou) {
+                ou_x = V3{__builtin_fma(ou_d, ou_x.x, ou_c * z0.x), __builtin_fma(ou_d, ou_x.y, ou_c * z0.y),
+                          __builtin_fma(ou_d, ou_x.z, ou_c * z0.z)};
+                z0 = ou_x;
+            }
             const V3 f = simple_stage<THERMAL, AXIS_Z, DEVPHYS>(m, k, kJ, z0, dv, true);
             mn = V3{__builtin_fma(dt, f.x, m.x), __builtin_fma(dt, f.y, m.y), __builtin_fma(dt, f.z, m.z)};   // simple_solver.py:275-276
         } else {
             V3 z0 = zero, z1 = zero, z2 = zero, z3 = zero;
-            if (THERMAL) {   // 12 normals = 6 Box-Muller pairs per sub-step
+            if (ou) {
+                const V3 xi = ns.draw((i & 1) == 0);
+                ou_x = V3{__builtin_fma(ou_d, ou_x.x, ou_c * xi.x), __builtin_fma(ou_d, ou_x.y, ou_c * xi.y),
+                          __builtin_fma(ou_d, ou_x.z, ou_c * xi.z)};
+                z0 = ou_x; z1 = ou_x; z2 = ou_x; z3 = ou_x;
+            } else if (THERMAL) {   // 12 normals = 6 Box-Muller pairs per sub-step
                 z0 = ns.draw(true); z1 = ns.draw(false); z2 = ns.draw(true); z3 = ns.draw(false);
             }
             const V3 f1 = simple_stage<THERMAL, AXIS_Z, DEVPHYS>(m, k, kJ, z0, dv, true);

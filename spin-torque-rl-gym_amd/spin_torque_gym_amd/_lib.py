@@ -26,6 +26,7 @@ class StgConfig(C.Structure):
         ("success_threshold", C.c_double), ("energy_penalty_weight", C.c_double),
         ("targets", (C.c_double * 3) * STG_MAX_TARGETS), ("seed", C.c_uint64), ("max_attempts", C.c_int64),
         ("skip_done", C.c_int32), ("torque_model", C.c_int32), ("wave_spec", C.c_int32), ("lane_sort", C.c_int32),
+        ("noise_model", C.c_int32), ("reserved", C.c_int32), ("noise_corr_time", C.c_double),
     ]
 
 

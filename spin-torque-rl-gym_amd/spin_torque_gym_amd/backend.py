@@ -37,6 +37,8 @@ class EnvConfig:
     torque_model: str = "reference"           # 'reference' (the env's type-agnostic RHS) | 'device' (opt-in)
     lane_sort: Optional[bool] = None          # duration-sorted lane schedule: None = automatic, True/False = force
     wave_spec: Optional[bool] = None          # producer/consumer wavefront pairs (thermal): None = automatic
+    noise_model: str = "white"                # 'white' (reference solvers) | 'ou' (ThermalFluctuations, fixed-step only)
+    correlation_time: float = 1e-12           # ThermalFluctuations.correlation_time, for noise_model='ou'
 
     def to_abi(self) -> "_lib.StgConfig":
         if self.solver not in _lib.SOLVERS:
@@ -63,6 +65,10 @@ class EnvConfig:
         c.torque_model = int(self.torque_model == "device")
         c.lane_sort = 0 if self.lane_sort is None else (1 if self.lane_sort else -1)
         c.wave_spec = 0 if self.wave_spec is None else (1 if self.wave_spec else -1)
+        if self.noise_model not in ("white", "ou"):
+            raise ValueError("noise_model must be 'white' or 'ou'")
+        c.noise_model = int(self.noise_model == "ou")
+        c.noise_corr_time = float(self.correlation_time)
         return c
 
 

@@ -94,6 +94,7 @@ class SpinTorqueVecEnv:
                  energy_penalty_weight: float = 0.1, solver: str = "rk4", seed: Optional[int] = None,
                  autoreset: bool = False, skip_done: bool = False, device_index: int = 0, env_id0: int = 0,
                  max_attempts: int = 200_000, lane_sort: Optional[bool] = None, wave_spec: Optional[bool] = None, torque_model: str = "reference",
+                 noise_model: str = "white", correlation_time: float = 1e-12,
                  backend=None):
         self.num_envs = int(num_envs)
         factory = DeviceFactory()
@@ -120,7 +121,7 @@ class SpinTorqueVecEnv:
                              energy_penalty_weight=energy_penalty_weight, target_states=[list(t) for t in targets],
                              seed=int(self._rng.integers(0, 2**63 - 1)) if seed is None else int(seed),
                              max_attempts=max_attempts, skip_done=skip_done, lane_sort=lane_sort, wave_spec=wave_spec,
-                             torque_model=torque_model)
+                             torque_model=torque_model, noise_model=noise_model, correlation_time=correlation_time)
         self.autoreset = bool(autoreset)
         # `backend` is a test seam: a class/callable with HipBackend's constructor signature (tests inject the CPU
         # oracle for the gloo runs and as the comparator); the product default is the HIP library, nothing else.

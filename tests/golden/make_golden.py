@@ -504,7 +504,20 @@ def G13():
     save("G13_array_env", **out)
 
 
-ALL = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11, G12=G12, G13=G13)
+def G14():
+    """thermal_ou: ThermalFluctuations.generate_thermal_field(correlated=True) sequences (thermal_model.py:113-137)."""
+    out = {}
+    cases = []
+    for seed, tau, dt in ((7, 1e-12, 1e-12), (11, 5e-12, 1e-12), (3, 1e-12, 2.5e-13), (5, 2e-13, 1e-12)):
+        tf = ThermalFluctuations(temperature=300.0, correlation_time=tau, seed=seed)
+        seq = np.array([tf.generate_thermal_field(0.01, 800e3, 1e-24, dt, correlated=True) for _ in range(64)])
+        out[f"field_{len(cases)}"] = seq
+        cases.append((seed, tau, dt, tf.compute_noise_strength(0.01, 800e3, 1e-24)))
+    out["cases"] = np.array(cases)
+    save("G14_thermal_ou", **out)
+
+
+ALL = dict(G14=G14, G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11, G12=G12, G13=G13)
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

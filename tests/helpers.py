@@ -23,7 +23,9 @@ def oracle_config(cfg):
                               max_steps=cfg.max_steps, max_current=cfg.max_current, max_duration=cfg.max_duration,
                               success_threshold=cfg.success_threshold, energy_penalty_weight=cfg.energy_penalty_weight,
                               seed=cfg.seed, max_attempts=cfg.max_attempts,
-                              torque_model=int(getattr(cfg, "torque_model", "reference") == "device"))
+                              torque_model=int(getattr(cfg, "torque_model", "reference") == "device"),
+                              noise_model=int(getattr(cfg, "noise_model", "white") == "ou"),
+                              noise_corr_time=getattr(cfg, "correlation_time", 1e-12))
 
 
 def oracle_params(table):

@@ -858,3 +858,48 @@ def test_pipelined_gather_overlaps_and_matches_sync(stg):
         e1.close(); e2.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("solver", ["rk4", "euler"])
+def test_ornstein_uhlenbeck_noise_model_vs_oracle(stg, solver):
+    """noise_model='ou' (ThermalFluctuations' correlated field) on the fixed-step kernels against the
+    oracle, same stream: one- and two-wavefront kernels, one class and a class table, two fused steps; RK45 refuses it."""
+    from helpers import OracleBackend, unit_rows
+    n = 320
+    rng = np.random.default_rng(31)
+    m0 = unit_rows(rng, n)
+    tgt = np.where(rng.integers(0, 2, (n, 1)) == 0, 1.0, -1.0) * np.array([[0.0, 0.0, 1.0]])
+    acts = [_uniform_actions(2e6, 1e-10, 3e-10)(rng, n, k) for k in range(2)]
+    vol = 1e-27                                  # strong field: the noise is most of the dynamics
+    for multi in (False, True):
+        if multi:
+            kw = dict(device_type=["stt_mram", "vcma_mram"],
+                      device_params=[stt_default_params(volume=vol), vcma_default_params(polarization=0.6, volume=vol * 0.8)],
+                      class_index=(np.arange(n) % 2).astype(np.uint8))
+        else:
+            kw = dict(device_params=stt_default_params(volume=vol))
+        kw.update(include_thermal_fluctuations=True, solver=solver, seed=13, noise_model="ou", correlation_time=3e-12,
+                  max_current=0.0 + 2e6)
+        res = []
+        for backend, ws in ((None, False), (None, True), (OracleBackend, None)):
+            env = stg.SpinTorqueVecEnv(n, backend=backend, wave_spec=ws, **kw)
+            env.reset(options={"initial_state": m0, "target_state": tgt})
+            out = []
+            for a in acts:
+                o, r, te, tr, info = env.step(torch.from_numpy(a * np.array([0.0, 1.0], dtype=np.float32)))   # J = 0: relaxation + noise
+                out.append((env.get_state()["m"].cpu().numpy().copy(), info["status"].cpu().numpy().copy()))
+            res.append(out)
+            env.close()
+        for k in range(2):
+            assert np.array_equal(res[0][k][0], res[1][k][0])                       # wave_spec on/off: bit-identical
+            assert np.array_equal(res[0][k][1], res[2][k][1])
+            d = np.abs(res[0][k][0] - res[2][k][0]).max()
+            assert d <= 1e-8, (solver, multi, k, d)     # the normals carry fp32 device transcendentals (1e-7 relative)
+        # the correlated field is not the white one
+        envw = stg.SpinTorqueVecEnv(n, **{**kw, "noise_model": "white"})
+        envw.reset(options={"initial_state": m0, "target_state": tgt})
+        envw.step(torch.from_numpy(acts[0] * np.array([0.0, 1.0], dtype=np.float32)))
+        assert np.abs(envw.get_state()["m"].cpu().numpy() - res[0][0][0]).max() > 1e-6
+        envw.close()
+    with pytest.raises(Exception):
+        stg.SpinTorqueVecEnv(8, solver="rk45", noise_model="ou")

@@ -186,6 +186,12 @@ def test_solver_facades_vs_golden(stg, golden):
     white = np.array([tf.generate_thermal_field(0.01, 800e3, params["volume"], 1e-12, correlated=False) for _ in range(4000)])
     assert np.allclose(white.std(axis=0), g8["tf_white_std"], rtol=1e-12)      # same seeded generator as the reference
     assert ThermalFluctuations(0.0).compute_noise_strength(0.01, 8e5, 1e-24) == 0.0
+    # the correlated (Ornstein-Uhlenbeck) sequences of the reference class, same seeds (G14)
+    g14 = golden("G14_thermal_ou")
+    for i, (seed, tau, dt, _) in enumerate(g14["cases"]):
+        tf = ThermalFluctuations(temperature=300.0, correlation_time=tau, seed=int(seed))
+        seq = np.array([tf.generate_thermal_field(0.01, 800e3, 1e-24, dt, correlated=True) for _ in range(64)])
+        assert np.array_equal(seq, g14[f"field_{i}"])
 
 
 def test_array_env_facade_vs_golden_g13(stg, golden):

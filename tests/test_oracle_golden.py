@@ -372,3 +372,39 @@ def test_g13_array_env(golden, oracle_mod):
         for m, h in zip(g["field_m"], g[f"field_{dev}"]):
             assert np.allclose(o.device_field(m, p), h, rtol=1e-14, atol=1e-9), dev
             assert np.allclose(device.compute_effective_field(m.copy(), np.zeros(3)), h, rtol=1e-14, atol=1e-9), dev
+
+
+def test_g14_ornstein_uhlenbeck_field(golden, oracle_mod):
+    """ThermalFluctuations' correlated field (thermal_model.py:113-137): the oracle's update, fed the white samples the
+    reference's seeded generator produced, reproduces the reference's field sequence; and a solve with noise_model = 1
+    is a solve whose thermal field is that recurrence over the kernels' own normal stream (held per sub-step)."""
+    g = golden("G14_thermal_ou")
+    for i, (seed, tau, dt, strength) in enumerate(g["cases"]):
+        rng = np.random.default_rng(int(seed))
+        x = np.zeros(3)
+        for k, ref in enumerate(g[f"field_{i}"]):
+            x = oracle_mod.ou_update(x, rng.normal(0, 1, 3), dt, tau)
+            assert np.allclose(strength * x, ref, rtol=1e-13, atol=0), (i, k)
+    # oracle solve with the OU field == hand-rolled RK4 over the same recurrence (Simple RHS from the oracle itself)
+    from conftest import stt_default_params
+    p = oracle_mod.make_params(stt_default_params(volume=1e-27))
+    T, J, tau = 3e-11, 0.0, 2e-12
+    c = oracle_mod.make_config(solver="rk4", thermal=True, seed=21, noise_model=1, noise_corr_time=tau)
+    m0 = np.array([0.3, 0.2, 0.93]); m0 /= np.linalg.norm(m0)
+    out = oracle_mod.simple_solve(m0, T, p, c, J, env_id=5, env_step=2)
+    n = out["n_steps"]
+    dt = T / n
+    hs = oracle_mod.thermal_strength(p, 2.21e5, 300.0, 0)   # SimpleLLGSSolver's constant
+    m, x = m0.copy(), np.zeros(3)
+    for i in range(n):
+        x = oracle_mod.ou_update(x, oracle_mod.thermal_normals(21, 5, 2, i), dt, tau)   # call i = sub-step i's normals
+        h = hs * x
+        t = i * dt
+        f = lambda y, ts: dt * oracle_mod.simple_dmdt(y, p, 2.21e5, J if ts <= T else 0.0, h)
+        k1 = f(m, t); k2 = f(m + k1 / 2, t + dt / 2); k3 = f(m + k2 / 2, t + dt / 2); k4 = f(m + k3, t + dt)
+        m = m + (((k1 + 2 * k2) + 2 * k3) + k4) / 6
+        m = m / np.linalg.norm(m)
+    assert np.abs(out["m_final"] - m).max() <= 1e-13
+    # and it is a different field from the white one
+    cw = oracle_mod.make_config(solver="rk4", thermal=True, seed=21)
+    assert np.abs(oracle_mod.simple_solve(m0, T, p, cw, J, env_id=5, env_step=2)["m_final"] - m).max() > 1e-9
