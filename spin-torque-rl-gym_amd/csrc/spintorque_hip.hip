@@ -259,14 +259,16 @@ __global__ void __launch_bounds__(PC ? 128 : 64) stg_step_kernel(const StepArgs 
         // producer wavefront: per env-step, wait for the consumer's stream position, then stay one chunk ahead
         // normals per chunk: RK45 6 (initial step) then 18 per attempt; RK4 12 per sub-step; Euler and the
         // Ornstein-Uhlenbeck field 3 per sub-step
-        const int n_first = SOLVER == STG_SOLVER_RK45 ? 6 : ((SOLVER == STG_SOLVER_RK4 && !(a.c.inv_tau > 0.0)) ? 12 : 3);
-        const int n_chunk = SOLVER == STG_SOLVER_RK45 ? 18 : n_first;
+        constexpr int n_first = SOLVER == STG_SOLVER_RK45 ? 6 : (SOLVER == STG_SOLVER_RK4 ? 12 : 3);
+        constexpr int n_chunk = SOLVER == STG_SOLVER_RK45 ? 18 : n_first;
+        const bool ou = a.c.inv_tau > 0.0;
         const double ghs = FIELD ? load_llgs(row).ghs : 0.0;
         for (int k = 0; k < a.K; ++k) {
             __syncthreads();                                       // H1: s_rng / s_go[k & 1] published
             if (!s_go[k & 1]) continue;
             const RngKey rk{a.c.seed, env_id, s_rng[lane]};
-            produce_normals<NT, FIELD>(s_norm, s_alive, lane, rk, n_first, n_chunk, ghs);
+            if (SOLVER == STG_SOLVER_RK4 && ou) produce_normals<NT, FIELD>(s_norm, s_alive, lane, rk, 3, 3, ghs);
+            else produce_normals<NT, FIELD>(s_norm, s_alive, lane, rk, n_first, n_chunk, ghs);
         }
         return;
     }

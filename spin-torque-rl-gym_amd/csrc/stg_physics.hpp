@@ -22,6 +22,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace stg {
 
@@ -489,15 +490,18 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
     // Ornstein-Uhlenbeck field (ThermalFluctuations._generate_correlated_noise, thermal_model.py:113-137), selected by a
     // wave-uniform inv_tau > 0: one update per sub-step, x <- d x + sqrt(1 - d^2) xi with d = exp(-dt/tau), and the same
     // x for every stage of the sub-step; the stream hands out three normals per sub-step, alternating phase like Euler's
-    const bool ou = THERMAL && inv_tau > 0.0;
+    const bool ou_sel = THERMAL && inv_tau > 0.0;
     double ou_d = 0.0, ou_c = 1.0;
     V3 ou_x = zero;
-    if (ou) {
+    if (ou_sel) {
         ou_d = exp(-dt * inv_tau);
         ou_c = sqrt(1.0 - ou_d * ou_d);
     }
     if (RECORD) rec.put(0, 0.0, m, 0.0);
-    // per-lane trip count n; with SharedNormals the loop is wave-uniform (lanes past their n idle inside the body)
+    // per-lane trip count n; with SharedNormals the loop is wave-uniform (lanes past their n idle inside the body).
+    // The loop exists twice (white / Ornstein-Uhlenbeck field), chosen once outside: `ou` is wave-uniform.
+    auto run = [&](auto ou_tag) {
+    constexpr bool ou = decltype(ou_tag)::value;
     for (int i = 0; NSRC::kShared || i < n; ++i) {
       if (i < n) {
         const bool last = (i == n - 1);
@@ -543,6 +547,8 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
       }
       if (NSRC::kShared && !ns.chunk_end(i + 1 < n)) break;
     }
+    };
+    if (THERMAL && ou_sel) run(std::true_type{}); else run(std::false_type{});
     const bool rejected_shared = NSRC::kShared && rejected_in;
     o.resets = rejected_shared ? 0 : resets;
     if (fail || rejected_shared) return o;
