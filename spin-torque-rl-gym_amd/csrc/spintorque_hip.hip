@@ -105,13 +105,13 @@ __device__ __forceinline__ LlgsEnergyK load_energy(const double* r) {
 
 template <int SOLVER, bool THERMAL, bool RECORD, bool AXIS_Z, bool DEVPHYS, class NSRC>
 __device__ __forceinline__ SolveOut run_solver(const V3& m, double J, double T, const double* row, const CfgView& c,
-                                               const RngKey& rk, const Recorder& rec, NSRC& ns) {
+                                               const RngKey& rk, const Recorder& rec, NSRC& ns, bool enabled) {
     if (SOLVER == STG_SOLVER_RK45) {
         const LlgsK k = load_llgs(row);
         LlgsEnergyK ek{};
         if (RECORD) ek = load_energy(row);
         return llgs_solve<THERMAL, RECORD, AXIS_Z>(m, J, T, k, row[C_BETA], row[C_BETAP], c.rtol, c.atol, c.max_step,
-                                                   c.max_attempts, rk, rec, ek, ns);
+                                                   c.max_attempts, rk, rec, ek, ns, enabled);
     }
     const SimpleK k = load_simple(row);
     DevTorque dv{0.0, 0.0, V3{0.0, 1.0, 0.0}, k.hk, false};
@@ -136,7 +136,7 @@ __device__ __forceinline__ SolveOut run_solver(const V3& m, double J, double T, 
         }
     }
     return simple_solve<SOLVER == STG_SOLVER_EULER ? 1 : 0, THERMAL, RECORD, AXIS_Z, DEVPHYS>(
-        m, J, T, k, pol, row[C_MSV], row[C_VALID] != 0.0, c.temperature, c.max_step, rk, rec, dv, ns, c.inv_tau);
+        m, J, T, k, pol, row[C_MSV], row[C_VALID] != 0.0, c.temperature, c.max_step, rk, rec, dv, ns, c.inv_tau, enabled);
 }
 
 // SpinTorqueEnv.reset draws (spin_torque_env.py:286-299) from the device generator: normal(0,1,3) normalised and a
@@ -208,56 +208,82 @@ constexpr int PLAN_ITEMS = 4;
 constexpr int TILE_ENVS = PLAN_THREADS * PLAN_ITEMS;   // 4096 envs sorted together (one plan workgroup)
 constexpr int TILE_WAVES = TILE_ENVS / 64;             // = 64 wavefronts of the step launch
 
-// Which 64-slot block of the schedule a workgroup takes.  With the sorted schedule, a tile's 64 wavefronts should share
-// an XCD (so its L2 merges their scattered accesses) and, across tiles, the longest wavefronts should start first.
-// Workgroups are observed to be dealt round-robin over the 8 XCDs (b % 8 labels the XCD group; a speed heuristic only,
-// never a correctness assumption): XCD group r takes tiles r, r+8, r+16, ... and walks them wave-rank-major
-// (rank 0 = longest wavefront of every tile first).  Tiles beyond the last complete group of 8 keep the identity map.
-__device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nblocks, bool sorted) {
-    if (!sorted) return b;
-    const uint32_t tiles8 = (nblocks / (8 * TILE_WAVES)) * 8;        // tiles in complete groups of 8
-    if (b >= tiles8 * TILE_WAVES) return b;
+// Which 64-slot block of the schedule integrating wavefront `cw` of workgroup `b` takes; a workgroup holds WGW = 1 or 4
+// integrating wavefronts.
+//  * WGW = 4 (launches of at least one such workgroup per CU): the dispatcher puts the wavefronts of a 256-thread
+//    workgroup on the four SIMDs of a CU one each, deterministically -- 64-thread workgroups were observed to double up
+//    on some SIMDs and leave others empty (tools/probes/wave_placement.hip: up to 104 of 1024 SIMDs with two wavefronts
+//    at 65 536 envs), which a launch with one wavefront per SIMD pays for in full.
+//  * With the sorted schedule, a tile's workgroups share an XCD (so its L2 merges their scattered accesses): workgroups
+//    are observed to be dealt round-robin over the 8 XCDs (b % 8 labels the XCD group; a speed heuristic only, never a
+//    correctness assumption), XCD group r takes tiles r, r+8, r+16, ... and walks them rank-major (longest wavefronts of
+//    every tile first).  Tiles beyond the last complete group of 8 keep the identity map.
+//  * Which wavefronts of a tile share a workgroup (= a CU): with one workgroup per CU, strided ranks u, u+16, u+32, u+48
+//    -- measured 1.96 ms against 2.23 ms for consecutive ranks on the RK45 step at 65 536 envs: four wavefronts that
+//    are busy for the whole launch slow each other down, a long one next to progressively shorter ones does not.
+template <int WGW>
+__device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool sorted, int cw) {
+    constexpr uint32_t TILE_WGS = TILE_WAVES / WGW;                   // workgroups per tile
+    if (!sorted) return (int64_t)b * WGW + cw;
+    const uint32_t tiles8 = (nwg / (8 * TILE_WGS)) * 8;              // tiles in complete groups of 8
+    if (b >= tiles8 * TILE_WGS) return (int64_t)b * WGW + cw;
     const uint32_t r = b % 8, q = b / 8;                              // XCD group, position inside the group
     const uint32_t tiles_per_xcd = tiles8 / 8;
-    const uint32_t w = q / tiles_per_xcd, t = (q % tiles_per_xcd) * 8 + r;
-    return (int64_t)t * TILE_WAVES + w;
+    const uint32_t u = q / tiles_per_xcd, t = (q % tiles_per_xcd) * 8 + r;
+    // one workgroup per CU at most (everything resident from the start): spread; otherwise keep wavefronts of similar
+    // duration together, so that a workgroup's four SIMD slots come free together for the next one (measured 6.0 ms
+    // against 7.6 ms at 262 144 envs)
+    const uint32_t rank = (nwg <= 256) ? (u + TILE_WGS * cw) : (WGW * u + cw);
+    return (int64_t)t * TILE_WAVES + rank;
 }
 
 // ------------------------------------------------------------------------------------------------
 // env.step kernel (A10-A14 around the solver), K fused steps per launch
 // ------------------------------------------------------------------------------------------------
-// PC = producer/consumer wave specialisation (thermal only): 128-thread workgroups whose first wavefront integrates 64
-// envs while the second runs the same envs' normal streams one chunk ahead into LDS (stg_physics.hpp: SharedNormals).
-// Same values in the same order, so results are identical; it pays when the launch is latency-bound (<= ~2 waves/SIMD).
-template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, bool DEVPHYS, typename AT, bool PC>
-__global__ void __launch_bounds__(PC ? 128 : 64) stg_step_kernel(const StepArgs a) {
+// Workgroup = WGW integrating wavefronts: 4 (256 envs, one wavefront per SIMD of the CU) for launches that fill the chip,
+// 1 for smaller ones (which then spread over four times as many CUs).
+// PC = producer/consumer wave specialisation (thermal only, launches of at most 65 536 envs): every integrating
+// wavefront gets a second wavefront that runs the normal streams of the same envs one chunk ahead into LDS
+// (stg_physics.hpp: SharedNormalsT).  Same values in the same order, so results are identical.  It is launched with
+// WGW = 1 (128-thread workgroups): the dispatcher was observed to put the two wavefronts on different SIMDs and to give
+// every SIMD one integrating and one producing wavefront at 65 536 envs (tools/probes/wave_placement.hip).  The code
+// supports WGW = 4 (producer 4+w serves integrating wavefront 3-w, all eight in lockstep) but that form measured no
+// better for RK45 and 8 % worse for RK4, so it is not instantiated.
+template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, bool DEVPHYS, typename AT, bool PC, int WGW>
+__global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) stg_step_kernel(const StepArgs a) {
     // the env-step arithmetic around the solver (energy, reward, flags) has no contraction: same roundings in every
     // instantiation, and the same as NumPy's
 #pragma clang fp contract(off)
     static_assert(!PC || THERMAL, "wave specialisation only exists for the thermal kernels");
     __shared__ double s_tab[MULTI ? STG_MAX_CLASSES * C_COUNT : 1];
-    // normals ring of the wave-specialised kernels: RK45 hands over finished fields (double), the fixed-step solvers raw
-    // normals (float)
+    // normals rings of the wave-specialised kernels (one per integrating wavefront): RK45 hands over finished fields
+    // (double), the fixed-step solvers raw normals (float)
     constexpr bool FIELD = SOLVER == STG_SOLVER_RK45;
     using NT = typename std::conditional<FIELD, double, float>::type;
-    __shared__ NT s_norm[PC ? 2 * SHARED_CHUNK_MAX * 64 : 1];
-    __shared__ int s_alive[2], s_go[2];
-    __shared__ unsigned long long s_cnt[3];
-    __shared__ uint32_t s_rng[PC ? 64 : 1];
-    const int lane = PC ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
-    const int64_t lane_slot = stg_slot_block(blockIdx.x, gridDim.x, a.perm != nullptr) * 64 + lane;
-    const bool in_range = lane_slot < a.N;
+    constexpr int RING = 2 * SHARED_CHUNK_MAX * 64;
+    __shared__ NT s_norm[PC ? WGW * RING : 1];
+    __shared__ int s_alive[2 * WGW], s_go[2 * WGW];
+    __shared__ unsigned long long s_cnt[WGW * 3];
+    __shared__ uint32_t s_rng[PC ? WGW * 64 : 1];
+    const int lane = (int)(threadIdx.x & 63u);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool producer = PC && wave >= WGW;
+    const int cw = producer ? (2 * WGW - 1 - wave) : wave;          // the integrating wavefront this one is, or serves
+    const int64_t lane_slot = stg_slot_block<WGW>(blockIdx.x, gridDim.x, a.perm != nullptr, cw) * 64 + lane;
+    const bool live = lane_slot < a.N;
     // duration-sorted schedule: slot j of the launch integrates env perm[j], so the 64 lanes of a wavefront have
     // (nearly) equal trip counts; all state and outputs stay at the env's own index
-    const int64_t i = in_range ? (a.perm ? (int64_t)a.perm[lane_slot] : lane_slot) : 0;
-    const double* row = class_row<MULTI>(a.ctab, a.cls, a.ncls, i, in_range, s_tab);
-    if (!in_range) return;      // (PC: whole lanes of both wavefronts leave; barriers are per wavefront)
+    const int64_t i = live ? (a.perm ? (int64_t)a.perm[lane_slot] : lane_slot) : 0;
+    const double* row = class_row<MULTI>(a.ctab, a.cls, a.ncls, i, live, s_tab);
+    // Lanes without an env: the one-wavefront form has no rendezvous after this point and lets them go; in the
+    // wave-specialised form they stay (inert) because every wavefront of the workgroup takes part in every s_barrier.
+    if (!PC && !live) return;
     const int64_t N = a.N;
     const uint64_t env_id = (uint64_t)(a.env_id0 + i);
 
-    if (PC && threadIdx.x >= 64) {
-        // producer wavefront: per env-step, wait for the consumer's stream position, then stay one chunk ahead
-        // normals per chunk: RK45 6 (initial step) then 18 per attempt; RK4 12 per sub-step; Euler and the
+    if (producer) {
+        // per env-step: wait for the stream positions (H1), then stay one chunk ahead of integrating wavefront `cw`.
+        // Normals per chunk: RK45 6 (initial step) then 18 per attempt; RK4 12 per sub-step; Euler and the
         // Ornstein-Uhlenbeck field 3 per sub-step
         constexpr int n_first = SOLVER == STG_SOLVER_RK45 ? 6 : (SOLVER == STG_SOLVER_RK4 ? 12 : 3);
         constexpr int n_chunk = SOLVER == STG_SOLVER_RK45 ? 18 : n_first;
@@ -265,15 +291,17 @@ __global__ void __launch_bounds__(PC ? 128 : 64) stg_step_kernel(const StepArgs 
         const double ghs = FIELD ? load_llgs(row).ghs : 0.0;
         for (int k = 0; k < a.K; ++k) {
             __syncthreads();                                       // H1: s_rng / s_go[k & 1] published
-            if (!s_go[k & 1]) continue;
-            const RngKey rk{a.c.seed, env_id, s_rng[lane]};
-            if (SOLVER == STG_SOLVER_RK4 && ou) produce_normals<NT, FIELD>(s_norm, s_alive, lane, rk, 3, 3, ghs);
-            else produce_normals<NT, FIELD>(s_norm, s_alive, lane, rk, n_first, n_chunk, ghs);
+            const int p = (k & 1) * WGW;
+            if (!any_flag<WGW>(s_go + p)) continue;
+            const bool serve = s_go[p + cw] != 0;
+            const RngKey rk{a.c.seed, env_id, s_rng[cw * 64 + lane]};
+            if (SOLVER == STG_SOLVER_RK4 && ou) produce_normals<NT, FIELD, WGW>(s_norm + cw * RING, s_alive, cw, lane, rk, 3, 3, ghs, serve);
+            else produce_normals<NT, FIELD, WGW>(s_norm + cw * RING, s_alive, cw, lane, rk, n_first, n_chunk, ghs, serve);
         }
         return;
     }
 
-    V3 m{a.s.mx[i], a.s.my[i], a.s.mz[i]};
+    V3 m{a.s.mx[i], a.s.my[i], a.s.mz[i]};          // (lanes without an env read env 0 and never write)
     V3 tgt{a.s.tx[i], a.s.ty[i], a.s.tz[i]};
     double etot = a.s.etot[i];
     int32_t step = a.s.step[i];
@@ -289,30 +317,39 @@ __global__ void __launch_bounds__(PC ? 128 : 64) stg_step_kernel(const StepArgs 
                          a.c.max_duration, J, T);
         const bool last = (k == a.K - 1);
         const int64_t ko = a.out_every ? k : 0;
-        const bool wr = a.out_every || last;
+        const bool wr = (a.out_every || last) && live;
         uint8_t st;
         double reward, energy = 0.0;
         bool is_success, truncated;
-        SharedNormalsT<NT, FIELD> shared{s_norm, s_alive, lane, 0, 0};
-        InlineNormals inl;
+        // with skip_done, finished envs are not integrated: a wavefront whose lanes are all done skips the integrator
+        const bool lane_solves = live && !(a.c.skip_done && done);
+        const RngKey rk{a.c.seed, env_id, rng};
+        SolveOut so{m, 0, 0, 0, false};
         if (PC) {
-            const bool wave_go = __ballot(!(a.c.skip_done && done)) != 0ull;
-            s_rng[lane] = rng;
-            s_go[k & 1] = wave_go ? 1 : 0;
+            // H1: this wavefront's stream positions and whether it integrates at all; then, if anybody in the workgroup
+            // does, H2 (chunk 0 is in LDS) and the solve, which every integrating wavefront of the workgroup walks chunk
+            // for chunk (lanes that do not integrate are inert)
+            SharedNormalsT<NT, FIELD, WGW> shared{s_norm + cw * RING, s_alive, cw, lane, 0, 0};
+            const int p = (k & 1) * WGW;
+            s_rng[cw * 64 + lane] = rng;
+            const bool mine = __ballot(lane_solves) != 0ull;
+            s_go[p + cw] = mine ? 1 : 0;
             __syncthreads();                                       // H1
-            if (wave_go) __syncthreads();                          // H2: chunk 0 is in LDS
+            if ((WGW == 1) ? mine : any_flag<WGW>(s_go + p)) {
+                __syncthreads();                                   // H2
+                so = run_solver<SOLVER, THERMAL, false, AXIS_Z, DEVPHYS>(m, J, T, row, a.c, rk, norec, shared, lane_solves);
+            }
         }
-        if (a.c.skip_done && done) {
-            // wavefront-level early-out: a wave whose lanes are all done skips the integrator entirely
+        if (!lane_solves) {
             st = STG_STATUS_INACTIVE; reward = 0.0;
             is_success = dot(m, tgt) >= a.c.thr;
             truncated = step >= a.c.max_steps;
         } else {
             const double prev_align = dot(m, tgt);                                   // spin_torque_env.py:338-339
-            const RngKey rk{a.c.seed, env_id, rng};
-            SolveOut so;
-            if (PC) so = run_solver<SOLVER, THERMAL, false, AXIS_Z, DEVPHYS>(m, J, T, row, a.c, rk, norec, shared);
-            else so = run_solver<SOLVER, THERMAL, false, AXIS_Z, DEVPHYS>(m, J, T, row, a.c, rk, norec, inl);
+            if (!PC) {
+                InlineNormals inl;
+                so = run_solver<SOLVER, THERMAL, false, AXIS_Z, DEVPHYS>(m, J, T, row, a.c, rk, norec, inl, true);
+            }
             if (fabs(J) > 1e-12) {                                                   // spin_torque_env.py:474-480
                 const V3 ref{row[C_REFX], row[C_REFY], row[C_REFZ]};
                 const double r = resistance(m, (int)row[C_DEVTYPE], row[C_RP], row[C_RAP], row[C_TMR], ref, row[C_RSERIES]);
@@ -342,7 +379,7 @@ __global__ void __launch_bounds__(PC ? 128 : 64) stg_step_kernel(const StepArgs 
         // same-step auto-reset: the finished episode's reward/flags go out with this step, the state is redrawn on the
         // device and the observation handed to the agent is the NEW episode's first one (the terminal observation goes
         // to final_obs when the caller asked for it)
-        const bool do_reset = a.autoreset && done;
+        const bool do_reset = a.autoreset && done && live;
         if (wr && do_reset && a.final_obs) write_obs(a.final_obs + ko * 12 * N, N, i, m, tgt, row, a.c, step, etot, J, T);
         if (do_reset) {
             device_reset_draw(a.c.seed, env_id, rng, a.c, true, true, m, tgt);
@@ -359,15 +396,17 @@ __global__ void __launch_bounds__(PC ? 128 : 64) stg_step_kernel(const StepArgs 
             if (a.status) a.status[ko * N + i] = st;
         }
     }
-    a.s.mx[i] = m.x; a.s.my[i] = m.y; a.s.mz[i] = m.z;
-    a.s.tx[i] = tgt.x; a.s.ty[i] = tgt.y; a.s.tz[i] = tgt.z;
-    a.s.etot[i] = etot;
-    a.s.step[i] = step;
-    a.s.rng[i] = rng;
-    a.s.done[i] = done ? 1 : 0;
+    if (live) {
+        a.s.mx[i] = m.x; a.s.my[i] = m.y; a.s.mz[i] = m.z;
+        a.s.tx[i] = tgt.x; a.s.ty[i] = tgt.y; a.s.tz[i] = tgt.z;
+        a.s.etot[i] = etot;
+        a.s.step[i] = step;
+        a.s.rng[i] = rng;
+        a.s.done[i] = done ? 1 : 0;
+    }
     // on-device metrics (the reference's EnvironmentMonitor/solver stats are host-side bookkeeping): one atomic per
-    // counter per wavefront
-    wave_add3(a.counters + (size_t)(blockIdx.x % COUNTER_STRIPES) * COUNTER_STRIDE, s_cnt, c_steps, c_sub, c_noop);
+    // counter per wavefront, into one of COUNTER_STRIPES copies
+    wave_add3(a.counters + (size_t)((blockIdx.x * WGW + cw) % COUNTER_STRIPES) * COUNTER_STRIDE, s_cnt + cw * 3, c_steps, c_sub, c_noop);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -385,7 +424,7 @@ __global__ void __launch_bounds__(64) stg_solve_kernel(const SolveArgs a) {
     const RngKey rk{a.c.seed, (uint64_t)(a.env_id0 + i), a.env_step};
     const Recorder rec{a.traj_t, a.traj_m, a.traj_e, N, i, a.traj_cap};
     InlineNormals ns;
-    const SolveOut so = run_solver<SOLVER, THERMAL, RECORD, false, false>(m0, a.J[i], a.T[i], row, a.c, rk, rec, ns);
+    const SolveOut so = run_solver<SOLVER, THERMAL, RECORD, false, false>(m0, a.J[i], a.T[i], row, a.c, rk, rec, ns, true);
     a.m_final[i] = so.m.x; a.m_final[N + i] = so.m.y; a.m_final[2 * N + i] = so.m.z;
     if (a.n_points) a.n_points[i] = so.n;
     if (a.success) a.success[i] = so.ok ? 1 : 0;
@@ -738,8 +777,9 @@ int stg_thermal_strength(stg_ctx* ctx, int32_t cls, double* out) {
     return STG_OK;
 }
 
-// largest launch the automatic wave specialisation applies to: 2 integrating wavefronts per SIMD (256 CUs x 4 SIMDs x 64)
-constexpr int64_t STG_WAVE_SPEC_MAX_ENVS = 2 * 65536;
+// largest launch the automatic wave specialisation applies to: one integrating wavefront per SIMD (256 CUs x 4 SIMDs x
+// 64 lanes); beyond that the launch is throughput-bound and the rendezvous costs more than it gives
+constexpr int64_t STG_WAVE_SPEC_MAX_ENVS = 65536;
 
 static inline dim3 grid_for(int64_t N) { return dim3((unsigned)((N + 63) / 64)); }
 
@@ -759,21 +799,33 @@ int stg_reset(stg_ctx* ctx, const uint8_t* mask, const double* init_m, const dou
 }
 
 extern "C++" {
+constexpr int64_t STG_WG4_MIN_ENVS = 65536;       // 256 CUs x 4 SIMDs x 64 lanes
+
+template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, bool DEVPHYS, int WGW>
+static void launch_step_w(const StepArgs& a, int act_f64, bool pc, hipStream_t st) {
+    const dim3 grid((unsigned)((a.N + WGW * 64 - 1) / (WGW * 64)));
+    if (act_f64)
+        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, double, false, WGW>), grid, dim3(WGW * 64), 0, st, a);
+    else
+        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, float, false, WGW>), grid, dim3(WGW * 64), 0, st, a);
+}
+
 template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, bool DEVPHYS>
 static void launch_step(const StepArgs& a, int act_f64, bool pc, hipStream_t st) {
     if (THERMAL && !DEVPHYS && pc) {
-        // wave-specialised variant (same grid, 2 wavefronts per workgroup); not built for the device-physics model
+        // wave-specialised variant: one integrating + one producing wavefront per workgroup; not built for the
+        // device-physics model
         constexpr bool PC = THERMAL && !DEVPHYS;
+        const dim3 grid((unsigned)((a.N + 63) / 64));
         if (act_f64)
-            hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, double, PC>), grid_for(a.N), dim3(128), 0, st, a);
+            hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, double, PC, 1>), grid, dim3(128), 0, st, a);
         else
-            hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, float, PC>), grid_for(a.N), dim3(128), 0, st, a);
+            hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, float, PC, 1>), grid, dim3(128), 0, st, a);
         return;
     }
-    if (act_f64)
-        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, double, false>), grid_for(a.N), dim3(64), 0, st, a);
-    else
-        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, float, false>), grid_for(a.N), dim3(64), 0, st, a);
+    // workgroups of 4 integrating wavefronts once there is one per CU, of 1 below that
+    if (a.N >= STG_WG4_MIN_ENVS) launch_step_w<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, 4>(a, act_f64, pc, st);
+    else launch_step_w<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, 1>(a, act_f64, pc, st);
 }
 template <int SOLVER, bool AXIS_Z, bool DEVPHYS>
 static void dispatch_step2(const StepArgs& a, bool thermal, bool multi, int act_f64, bool pc, hipStream_t st) {

@@ -236,34 +236,50 @@ constexpr int SHARED_CHUNK_MAX = 18;     // normals per chunk: RK45 attempt 18, 
 // T = float: raw normals (fixed-step solvers, whose producer is the critical wavefront and should do no extra work);
 // T = double, SCALED: the finished thermal field c * z (RK45, whose producer has slack: the integrating wavefront
 // saves the conversions and the scaling of every RHS call).
-template <typename T, bool SCALED>
+// A workgroup holds WGW integrating wavefronts (1 or 4) and as many producers; s_barrier is workgroup-wide, so all of
+// them run chunk for chunk in lockstep until the last integrating wavefront is through: `alive` has one flag per
+// integrating wavefront (two copies, alternating per chunk) and everybody ORs them after the rendezvous.
+template <int WGW>
+__device__ __forceinline__ bool any_flag(volatile int* f) {
+    int v = f[0];
+#pragma unroll
+    for (int j = 1; j < WGW; ++j) v |= f[j];
+    return v != 0;
+}
+
+template <typename T, bool SCALED, int WGW>
 struct SharedNormalsT {
     static constexpr bool kShared = true, kScaled = SCALED;
-    const T* buf;           // LDS [2][SHARED_CHUNK_MAX][64]
-    volatile int* alive;    // LDS [2]: does the consumer wave continue after chunk `it`?
-    int lane, it, idx;
+    const T* buf;           // this wavefront's LDS ring [2][SHARED_CHUNK_MAX][64]
+    volatile int* alive;    // LDS [2][WGW]
+    int cw, lane, it, idx;
     __device__ __forceinline__ void begin(const RngKey&) { it = 0; idx = 0; }
     __device__ __forceinline__ V3 draw(bool) {
         const T* b = buf + ((it & 1) * SHARED_CHUNK_MAX + idx) * 64 + lane;
         idx += 3;
         return V3{(double)b[0], (double)b[64], (double)b[128]};
     }
-    // end of the consumer's chunk: wave-uniform decision, published for the producer, then the rendezvous
+    // end of a chunk: this wavefront's (wave-uniform) wish to continue is published, then the rendezvous; returns
+    // whether ANY integrating wavefront of the workgroup continues
     __device__ __forceinline__ bool chunk_end(bool lane_continues) {
-        const bool any = __ballot(lane_continues) != 0ull;
-        alive[it & 1] = any ? 1 : 0;
+        const int p = (it & 1) * WGW;
+        const bool mine = __ballot(lane_continues) != 0ull;
+        alive[p + cw] = mine ? 1 : 0;
         __syncthreads();
+        const bool any = (WGW == 1) ? mine : any_flag<WGW>(alive + p);    // (no LDS round trip when it is our own flag)
         ++it;
         idx = 0;
         return any;
     }
 };
 
-// The producer wavefront's side for one solve: chunk 0 has n_first normals, later chunks n_chunk; calls alternate
-// between the even and odd phase of the stream across chunk boundaries, exactly as the integrator's calls do.
-template <typename T, bool SCALED>
-__device__ __forceinline__ void produce_normals(T* buf, volatile int* alive, int lane, const RngKey& rk, int n_first,
-                                                int n_chunk, double c) {
+// The producer wavefront's side for one solve of the integrating wavefront `served`: chunk 0 has n_first normals, later
+// chunks n_chunk; calls alternate between the even and odd phase of the stream across chunk boundaries, exactly as the
+// integrator's calls do.  It stays one chunk ahead while its own integrating wavefront is alive (`serve`), and keeps
+// taking part in the workgroup's rendezvous until the last one is through.
+template <typename T, bool SCALED, int WGW>
+__device__ __forceinline__ void produce_normals(T* buf, volatile int* alive, int served, int lane, const RngKey& rk,
+                                                int n_first, int n_chunk, double c, bool serve) {
     NormalStream ns;
     ns.init(rk.seed, rk.env_id, rk.env_step, 0u);
     int it = 0;
@@ -281,12 +297,14 @@ __device__ __forceinline__ void produce_normals(T* buf, volatile int* alive, int
             b[(j + 0) * 64] = (T)z.x; b[(j + 1) * 64] = (T)z.y; b[(j + 2) * 64] = (T)z.z;
         }
     };
-    fill(0, n_first);
-    __syncthreads();                                   // chunk 0 ready (the consumer waits here too)
+    if (serve) fill(0, n_first);
+    __syncthreads();                                   // chunk 0 ready (the integrating wavefronts wait here too)
     for (;;) {
-        fill((it + 1) & 1, n_chunk);                   // next chunk, while the consumer works on chunk `it`
-        __syncthreads();                               // = the consumer's chunk_end rendezvous
-        const bool go = alive[it & 1] != 0;
+        if (serve) fill((it + 1) & 1, n_chunk);        // next chunk, while the integrating wavefront works on chunk `it`
+        __syncthreads();                               // = the integrating wavefronts' chunk_end rendezvous
+        const int p = (it & 1) * WGW;
+        serve = serve && alive[p + served] != 0;
+        const bool go = any_flag<WGW>(alive + p);
         ++it;
         if (!go) break;
     }
@@ -454,11 +472,13 @@ template <int METHOD, bool THERMAL, bool RECORD, bool AXIS_Z, bool DEVPHYS, clas
 __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double T, const SimpleK& k, double pol,
                                                  double msv, bool class_valid, double temperature, double max_step,
                                                  const RngKey& rk, const Recorder& rec, const DevTorque& dv, NSRC& ns,
-                                                 double inv_tau) {
+                                                 double inv_tau, bool enabled) {
 #pragma clang fp contract(off)
     SolveOut o{m0, 0, 0, 0, false};
     // robust_solver.py:152-190 (_validate_inputs); any failure ends in the fallback result (:140-150)
-    const bool rejected_in = validation_rejects(m0) || !(T > 0.0) || !class_valid || !(temperature > 0.0);
+    // `enabled` = false: a lane that only walks the workgroup's chunk loop (SharedNormals; no env behind it, or one
+    // that is not stepped this time)
+    const bool rejected_in = !enabled || validation_rejects(m0) || !(T > 0.0) || !class_valid || !(temperature > 0.0);
     if (!NSRC::kShared && rejected_in) return o;
     V3 m = m0;
     bool zr;
@@ -610,7 +630,7 @@ template <bool THERMAL, bool RECORD, bool AXIS_Z, class NSRC>
 __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T, const LlgsK& k, double beta,
                                                double betap, double rtol, double atol, double max_step,
                                                int64_t max_attempts, const RngKey& rk, const Recorder& rec,
-                                               const LlgsEnergyK& ek, NSRC& ns) {
+                                               const LlgsEnergyK& ek, NSRC& ns, bool enabled) {
     // Dormand-Prince tableau (rk.py:380-391)
     constexpr double A21 = 1.0 / 5;
     constexpr double A31 = 3.0 / 40, A32 = 9.0 / 40;
@@ -677,7 +697,7 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
     h_abs = h_abs > max_step ? max_step : (h_abs < min_step ? min_step : h_abs);          // rk.py:121-126
     // SharedNormals: the prologue's two RHS calls were chunk 0; every attempt is one further chunk and the loop is
     // wave-uniform (a finished lane idles until the wavefront's last lane is through)
-    bool active = (t != T);
+    bool active = enabled && (t != T);       // (a disabled lane only walks the workgroup's chunk loop)
     bool wave_go = true;
     if (NSRC::kShared) wave_go = ns.chunk_end(active);
     if (wave_go)

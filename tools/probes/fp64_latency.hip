@@ -57,6 +57,8 @@ int main() {
         run<1, 0>("fma_f64", 1024); run<3, 0>("fma_f64", 1024); run<3, 0>("fma_f64", 2048);
     }
     { int act = 64; hipMemcpyToSymbol(HIP_SYMBOL(g_active), &act, 4); }
+    printf("-- one wavefront per CU (256 x 64) vs four (1024 x 64 / 256 x 256 below)\n");
+    run<1, 3>("rsq_f64", 256); run<3, 3>("rsq_f64", 256); run<1, 4>("rcp_f64", 256); run<3, 0>("fma_f64", 256);
     for (int blocks : {1024, 2048}) {
         run<1, 0>("fma_f64", blocks); run<2, 0>("fma_f64", blocks); run<3, 0>("fma_f64", blocks); run<4, 0>("fma_f64", blocks);
         run<1, 1>("mul_f64", blocks); run<3, 1>("mul_f64", blocks);

@@ -45,6 +45,13 @@ int main(int argc, char** argv) {
             printf("\n"); ++shown;
         }
     }
+    // for SIMDs holding waves of several workgroups: histogram of (block of an even wave - block of an odd wave) / 8
+    std::map<int,int> dh;
+    for (auto& kv : m) for (auto& p : kv.second) for (auto& q : kv.second)
+        if (p.second % 2 == 0 && q.second % 2 == 1 && p.first != q.first) dh[((p.first - q.first) % blocks + blocks) % blocks]++;
+    printf("block(even wave) - block(odd wave) mod nblocks on shared SIMDs:");
+    for (auto& kv : dh) printf(" %d:%d", kv.first, kv.second);
+    printf("\n");
     printf("SIMDs used: %zu\n", m.size());
     for (auto& kv : hist) printf("  SIMDs holding %d waves: %d\n", kv.first, kv.second);
     for (auto& kv : same_role) printf("  SIMDs with %d even-index waves out of %d: %d\n", kv.first / 10, kv.first % 10, kv.second);
