@@ -187,7 +187,8 @@ struct NormalStream {
     }
     // uniform in (0,1) with 23-bit resolution: top 23 bits become the mantissa of a float in [1,2), minus (1 - 2^-24)
     __device__ __forceinline__ float uniform() {
-        return __uint_as_float((next() >> 9) | 0x3F800000u) - 0.99999994f;
+        // (v_alignbit_b32 forms {0x7f, x} >> 9 = 0x3F800000 | (x >> 9) in one instruction)
+        return __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, next(), 9u)) - 0.99999994f;
     }
     __device__ __forceinline__ void pair(float& a, float& b) {
         const float u0 = uniform();

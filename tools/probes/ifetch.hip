@@ -8,10 +8,15 @@
 #define R16(X) R4(R4(X))
 #define R64(X) R4(R16(X))
 #define R128(X) R64(X) R64(X)
+__device__ int g_phase = 0;
 template <int MODE>
 __global__ void k(double* out, const double* in, int iters) {
     double x0 = in[threadIdx.x & 63], x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3;
     const double a = in[64 + (threadIdx.x & 63)], b = in[128 + (threadIdx.x & 63)];
+    if (g_phase) {                              // put the wavefronts of a CU out of phase with each other
+        const int skew = ((threadIdx.x >> 6) * 131 + blockIdx.x * 37) % 509;
+        for (int i = 0; i < skew; ++i) { FMA4 }
+    }
     for (int i = 0; i < iters; ++i) {
         if (MODE == 0) { R4(FMA4) }            // 16 instr, 128 B
         if (MODE == 1) { R128(FMA4) }          // 512 instr, 4 KB
@@ -34,6 +39,8 @@ int main() {
     double *o, *in; hipMalloc(&o, 4096 * 512 * 8); hipMalloc(&in, 192 * 8);
     double h[192]; for (int i = 0; i < 192; ++i) h[i] = 1.0 + 1e-9 * i; hipMemcpy(in, h, sizeof h, hipMemcpyHostToDevice);
     for (int rep = 0; rep < 2; ++rep) {
+        hipMemcpyToSymbol(HIP_SYMBOL(g_phase), &rep, 4);
+        printf("-- wavefronts %s\n", rep ? "out of phase" : "in phase");
         run<0>("body 16 x fma (128 B)", 256, 256, 16, o, in);
         run<1>("body 512 x fma (4 KB)", 256, 256, 512, o, in);
         run<2>("body 2048 x fma (16 KB)", 256, 256, 2048, o, in);
