@@ -250,7 +250,10 @@ __device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool
 // supports WGW = 4 (producer 4+w serves integrating wavefront 3-w, all eight in lockstep) but that form measured no
 // better for RK45 and 8 % worse for RK4, so it is not instantiated.
 template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, bool DEVPHYS, typename AT, bool PC, int WGW>
-__global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) stg_step_kernel(const StepArgs a) {
+#ifndef STG_STEP_ATTR
+#define STG_STEP_ATTR
+#endif
+__global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR stg_step_kernel(const StepArgs a) {
     // the env-step arithmetic around the solver (energy, reward, flags) has no contraction: same roundings in every
     // instantiation, and the same as NumPy's
 #pragma clang fp contract(off)
