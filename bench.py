@@ -107,6 +107,11 @@ def run_config(n_local, solver, thermal, steps, warmup, rank, world, device_inde
         env = stg.SpinTorqueVecEnv(n_local, device_index=device_index, class_index=cls_global, **kw)
         backend = env.backend
     dev = backend.device
+    if world > 1:
+        # communicator set-up (lazy in RCCL) must not land in the timed block whatever --warmup is: one untimed gather
+        env.gather_begin()
+        env.gather_end(unpack=False)
+        torch.cuda.synchronize(dev)
     acts = make_actions(warmup + steps, n_local, dev, seed + 17 * rank)
     env.reset(seed=seed) if world == 1 else env.reset(seed=seed + rank, gather=False)
 
