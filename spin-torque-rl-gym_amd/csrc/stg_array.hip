@@ -205,6 +205,118 @@ __global__ void __launch_bounds__(64) stg_array_step_kernel(const ArrArgs a) {
     a.trunc[i] = step >= a.max_steps ? 1 : 0;
 }
 
+// 'individual' action mode (one addressed cell per step): nothing but that one cell changes, so the step is ONE streaming
+// pass over the array -- pattern and target in, both halves of the observation out, similarity, norm statistics and the
+// addressed cell's coupling sum accumulated on the way -- with no per-lane copy of the pattern in LDS.  Only the coupling
+// matrix sits in LDS (shared by the workgroup), so occupancy is set by registers, not by 24 KB of LDS per wavefront, and
+// the kernel keeps far more loads in flight.  Same arithmetic as the general kernel except the population standard
+// deviation of the cell norms (uniformity term), which is formed in one pass from e_j = |m_j| - 1 (the norms are 1 to
+// rounding, so sum(e^2)/n - mean(e)^2 has no cancellation problem at the 1e-16 level the quantity lives at).
+__global__ void __launch_bounds__(256) stg_array_step_individual_kernel(const ArrArgs a) {
+    extern __shared__ double lds[];           // coupling [n*n]
+    const int n = a.rows * a.cols;
+    double* lc = lds;
+    if (a.include_coupling) {
+        for (int q = threadIdx.x; q < n * n; q += blockDim.x) lc[q] = a.coupling[q];
+        __syncthreads();
+    }
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.N) return;
+    const int64_t N = a.N;
+    // _apply_action (array_env.py:411-445)
+    double J = (double)a.actions[N + i];
+    double T = (double)a.actions[2 * N + i];
+    J = isnan(J) ? J : fmin(fmax(J, -a.max_current), a.max_current);
+    T = isnan(T) ? T : fmin(fmax(T, 1e-12), a.max_duration);
+    const double a0 = (double)a.actions[i];
+    // int(np.clip(action[0], 0, n-1)); a NaN index raises in the reference -- here it addresses nothing
+    const int d = isnan(a0) ? -1 : (int)fmin(fmax(a0, 0.0), (double)(n - 1));
+    const bool drive = fabs(J) > 1e-12 && d >= 0;                                      // array_env.py:506
+    const double* crow = lc + (d >= 0 ? d : 0) * n;
+    double sim_sum = 0.0, se = 0.0, se2 = 0.0;
+    V3 m0{0.0, 0.0, 1.0}, tg{0.0, 0.0, 1.0}, hc{0.0, 0.0, 0.0};
+    double e_d = 0.0;
+    for (int j = 0; j < n; ++j) {
+        const V3 pv{a.pattern[(int64_t)(j * 3) * N + i], a.pattern[(int64_t)(j * 3 + 1) * N + i], a.pattern[(int64_t)(j * 3 + 2) * N + i]};
+        const V3 tv{a.target[(int64_t)(j * 3) * N + i], a.target[(int64_t)(j * 3 + 1) * N + i], a.target[(int64_t)(j * 3 + 2) * N + i]};
+        a.obs[obs_row_target(a.obs_mode, n, j, 0) * N + i] = (float)tv.x;
+        a.obs[obs_row_target(a.obs_mode, n, j, 1) * N + i] = (float)tv.y;
+        a.obs[obs_row_target(a.obs_mode, n, j, 2) * N + i] = (float)tv.z;
+        a.obs[obs_row_pattern(a.obs_mode, n, j, 0) * N + i] = (float)pv.x;          // (the addressed cell is rewritten below)
+        a.obs[obs_row_pattern(a.obs_mode, n, j, 1) * N + i] = (float)pv.y;
+        a.obs[obs_row_pattern(a.obs_mode, n, j, 2) * N + i] = (float)pv.z;
+        sim_sum += pv.x * tv.x; sim_sum += pv.y * tv.y; sim_sum += pv.z * tv.z;       // same order as the general kernel
+        const double e = sqrt(dot(pv, pv)) - 1.0;
+        se += e; se2 += e * e;
+        if (j == d) { m0 = pv; tg = tv; e_d = e; }
+        if (a.include_coupling && drive) {                                             // array_env.py:485-492
+            const double c = (j == d) ? 0.0 : crow[j];
+            hc = V3{hc.x + c * pv.x, hc.y + c * pv.y, hc.z + c * pv.z};
+        }
+    }
+    const double prev_sim = sim_sum / n;                                               // array_env.py:372-373
+    double e_total = 0.0;
+    if (drive) {
+        V3 h = device_field(m0, a.dev);
+        if (a.include_coupling) h = V3{h.x + hc.x, h.y + hc.y, h.z + hc.z};
+        // _simulate_device_dynamics (array_env.py:496-521): alpha = 0.01, gamma = 2.21e5, p_hat = z
+        const V3 mxp{m0.y, -m0.x, 0.0};
+        const V3 t2 = cross(m0, mxp);
+        const double tj = 0.1 * J;
+        const V3 mxh = cross(m0, h);
+        V3 dm{-2.21e5 * mxh.x, -2.21e5 * mxh.y, -2.21e5 * mxh.z};
+        const V3 mxdm = cross(m0, dm);
+        dm = V3{dm.x + 0.01 * mxdm.x + tj * t2.x, dm.y + 0.01 * mxdm.y + tj * t2.y, dm.z + 0.01 * mxdm.z + tj * t2.z};
+        const double dt = T / 10;
+        V3 m = m0;
+#pragma unroll
+        for (int it = 0; it < 10; ++it) {
+            m = V3{m.x + dm.x * dt, m.y + dm.y * dt, m.z + dm.z * dt};
+            const double inv = rsqrt_fast(dot(m, m));           // m / |m| (array_env.py:518), <= 2 ulp per component
+            m = V3{m.x * inv, m.y * inv, m.z * inv};
+        }
+        a.pattern[(int64_t)(d * 3) * N + i] = m.x;
+        a.pattern[(int64_t)(d * 3 + 1) * N + i] = m.y;
+        a.pattern[(int64_t)(d * 3 + 2) * N + i] = m.z;
+        a.obs[obs_row_pattern(a.obs_mode, n, d, 0) * N + i] = (float)m.x;
+        a.obs[obs_row_pattern(a.obs_mode, n, d, 1) * N + i] = (float)m.y;
+        a.obs[obs_row_pattern(a.obs_mode, n, d, 2) * N + i] = (float)m.z;
+        sim_sum += dot(m, tg) - dot(m0, tg);
+        const double e_new = sqrt(dot(m, m)) - 1.0;
+        se += e_new - e_d; se2 += e_new * e_new - e_d * e_d;
+        // energy with the resistance of the UPDATED state (current_m is a view of the pattern, array_env.py:455-463)
+        const V3 ref{a.dev.refx, a.dev.refy, a.dev.refz};
+        const double r = resistance(m, a.dev.dev_type, a.dev.r_p, a.dev.r_ap, a.dev.tmr, ref, a.dev.r_series);
+        const double v = J * r * a.dev.area;
+        e_total = (v * v) / r * T;
+    }
+    const double etot = a.etot[i] + e_total;
+    const int32_t step = a.step[i] + 1;
+    a.etot[i] = etot;
+    a.step[i] = step;
+    const double sim = sim_sum / n;
+    const bool is_success = sim >= a.thr;
+    if (a.obs_mode == 1) {
+        a.obs[(int64_t)(6 * n + 0) * N + i] = (float)sim;
+        a.obs[(int64_t)(6 * n + 1) * N + i] = (float)((double)(a.max_steps - step) / (double)a.max_steps);
+        a.obs[(int64_t)(6 * n + 2) * N + i] = (float)(etot / 1e-12);
+        a.obs[(int64_t)(6 * n + 3) * N + i] = (float)(a.temperature / 300.0);
+    }
+    // uniformity = 1 - population std of the cell norms (array_env.py:216-224)
+    const double me = se / n;
+    const double var = fmax(se2 / n - me * me, 0.0);
+    const double uniformity = fmax(0.0, 1.0 - sqrt(var));
+    double reward = 10.0 * (is_success ? 10.0 : sim * 5.0);                            // array_env.py:183-224
+    reward += (-a.w_energy) * (-e_total / 1e-12);
+    reward += (sim - prev_sim);
+    reward += 2.0 * uniformity;
+    a.reward[i] = (float)reward;
+    if (a.reward64) a.reward64[i] = reward;
+    if (a.energy) a.energy[i] = e_total;
+    a.term[i] = is_success ? 1 : 0;
+    a.trunc[i] = step >= a.max_steps ? 1 : 0;
+}
+
 struct ArrResetArgs {
     int64_t N, env_id0;
     int32_t rows, cols, max_steps, obs_mode;
@@ -390,6 +502,14 @@ int stg_array_step(stg_array_ctx* ctx, const float* actions, float* obs, float* 
     a.actions = actions; a.obs = obs; a.reward = reward; a.reward64 = reward_f64; a.energy = energy; a.term = terminated;
     a.trunc = truncated;
     const int n = c.rows * c.cols;
+    if (c.action_mode == 0) {
+        // one addressed cell per step: streaming kernel, only the coupling matrix in LDS (<= 32 KB at 8 x 8)
+        const size_t lds_c = c.include_coupling ? sizeof(double) * (size_t)n * n : 0;
+        hipLaunchKernelGGL(stg_array_step_individual_kernel, dim3((unsigned)((ctx->N + 255) / 256)), dim3(256), lds_c,
+                           (hipStream_t)stream, a);
+        AHIP_TRY(hipGetLastError());
+        return STG_OK;
+    }
     const size_t lds = sizeof(double) * ((size_t)n * 3 * 64 + (c.include_coupling ? (size_t)n * n : 0));
     if (lds > 48 * 1024)
         AHIP_TRY(hipFuncSetAttribute((const void*)stg_array_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
