@@ -903,3 +903,35 @@ def test_ornstein_uhlenbeck_noise_model_vs_oracle(stg, solver):
         envw.close()
     with pytest.raises(Exception):
         stg.SpinTorqueVecEnv(8, solver="rk45", noise_model="ou")
+
+
+@pytest.mark.parametrize("solver", ["rk4", "euler", "rk45"])
+def test_randomised_configurations_vs_oracle(stg, solver):
+    """Randomised cross-check: device parameters drawn inside the validator's ranges (incl. tilted easy axes, demag
+    factors, damping up to 0.3), log-uniform float32 pulse durations from the 1 ps minimum upwards (the roundings behind
+    H4/H5 and the RK45 pulse gate), currents from 0 to the limit, thermal off and on, two steps each -- HIP vs oracle."""
+    rng = np.random.default_rng({"rk4": 101, "euler": 202, "rk45": 303}[solver])
+    n = 96
+    worst = 0.0
+    for case in range(6):
+        thermal = bool(case & 1)
+        vol = float(10 ** rng.uniform(-11.5, -10) if solver != "rk45" else 10 ** rng.uniform(-5.7, -4.5))
+        axis = np.array([0.0, 0.0, 1.0]) if case < 2 else np.array([rng.normal(0, 0.3), rng.normal(0, 0.3), 1.0])
+        par = stt_default_params(volume=vol, damping=float(10 ** rng.uniform(-2.3, -0.5)),
+                                 saturation_magnetization=float(rng.uniform(4e5, 1.2e6)),
+                                 uniaxial_anisotropy=float(rng.uniform(3e5, 1.5e6)), easy_axis=axis,
+                                 polarization=float(rng.uniform(0.2, 0.9)))
+        if case >= 4:
+            par["demag_factors"] = np.array([0.1, 0.25, 0.65])
+        tmax = 2e-10 if solver == "rk45" else 1.5e-9
+
+        def actions(arng, k, s, tmax=tmax):
+            a = np.empty((k, 2), dtype=np.float32)
+            a[:, 0] = arng.uniform(-2e6, 2e6, k) * (arng.uniform(0, 1, k) > 0.15)          # some exact zeros
+            a[:, 1] = 10 ** arng.uniform(-12.2, np.log10(tmax), k)                        # below the 1 ps clamp too
+            return a
+        outs = _run_pair(stg, n, 2, actions, seed=1000 + case, device_params=par, include_thermal_fluctuations=thermal,
+                         solver=solver, max_duration=5e-9)
+        tol = (TOL_RK45 if solver == "rk45" else TOL_RK4) * (50 if thermal else 1)       # normals carry fp32 device transcendentals
+        worst = max(worst, _compare(outs, tol))
+    print(solver, "randomised configurations: worst |dm| =", worst)
