@@ -222,9 +222,19 @@ constexpr int TILE_WAVES = TILE_ENVS / 64;             // = 64 wavefronts of the
 //    -- measured 1.96 ms against 2.23 ms for consecutive ranks on the RK45 step at 65 536 envs: four wavefronts that
 //    are busy for the whole launch slow each other down, a long one next to progressively shorter ones does not.
 template <int WGW>
-__device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool sorted, int cw) {
+__device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool sorted, int cw, bool pairs) {
     constexpr uint32_t TILE_WGS = TILE_WAVES / WGW;                   // workgroups per tile
     if (!sorted) return (int64_t)b * WGW + cw;
+    if (WGW == 1 && pairs && nwg == 1024) {
+        // Wave-specialised launch with exactly one integrating wavefront per SIMD (65 536 envs; 16 tiles, two per XCD
+        // group).  Observed placement (tools/probes/wave_placement.hip, 1024 x 128 threads): a CU takes the workgroups
+        // q, q+32, q+64, q+96 of its XCD group and the producer of arrival g shares a SIMD with the integrating
+        // wavefront of arrival g+1 (cyclically).  Arrivals alternate between the long half of a tile (ranks j) and the
+        // short half (ranks 63-j): every long integrating wavefront then shares its SIMD with the producer of a short
+        // one, which retires early, and its own producer runs next to a short integrating wavefront.
+        const uint32_t r = b % 8, q = b / 8, g = q / 32, j = q % 32;
+        return (int64_t)((g >> 1) * 8 + r) * TILE_WAVES + ((g & 1) ? (TILE_WAVES - 1 - j) : j);
+    }
     const uint32_t tiles8 = (nwg / (8 * TILE_WGS)) * 8;              // tiles in complete groups of 8
     if (b >= tiles8 * TILE_WGS) return (int64_t)b * WGW + cw;
     const uint32_t r = b % 8, q = b / 8;                              // XCD group, position inside the group
@@ -272,7 +282,7 @@ __global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR st
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const bool producer = PC && wave >= WGW;
     const int cw = producer ? (2 * WGW - 1 - wave) : wave;          // the integrating wavefront this one is, or serves
-    const int64_t lane_slot = stg_slot_block<WGW>(blockIdx.x, gridDim.x, a.perm != nullptr, cw) * 64 + lane;
+    const int64_t lane_slot = stg_slot_block<WGW>(blockIdx.x, gridDim.x, a.perm != nullptr, cw, PC) * 64 + lane;
     const bool live = lane_slot < a.N;
     // duration-sorted schedule: slot j of the launch integrates env perm[j], so the 64 lanes of a wavefront have
     // (nearly) equal trip counts; all state and outputs stay at the env's own index
