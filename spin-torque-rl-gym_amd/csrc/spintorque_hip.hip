@@ -1029,6 +1029,12 @@ int stg_device_terms(stg_ctx* ctx, const double* m, const double* J, const doubl
     return STG_OK;
 }
 
+#ifdef STG_PROFILE_LOOP
+int stg_debug_prof(long long* out) {          // experiment builds only
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(stg::g_stg_prof), 16 * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 int stg_get_counters(stg_ctx* ctx, uint64_t* out, int32_t reset) {
     if (!ctx || !out) return fail(STG_E_INVALID, "ctx/out is NULL");
     HIP_TRY(hipSetDevice(ctx->device));

@@ -523,8 +523,11 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
     // The loop exists twice (white / Ornstein-Uhlenbeck field), chosen once outside: `ou` is wave-uniform.
     auto run = [&](auto ou_tag) {
     constexpr bool ou = decltype(ou_tag)::value;
-    for (int i = 0; NSRC::kShared || i < n; ++i) {
-      if (i < n) {
+    for (int i = 0;; ++i) {
+      // wave-uniform loop, branch-free body: a lane past its n walks along with its state frozen (see llgs_solve)
+      const bool act = i < n;
+      if (!NSRC::kShared && __ballot(act) == 0ull) break;
+      {
         const bool last = (i == n - 1);
         const double kJ2 = last ? kJ2_last : kJ, kJ4 = last ? kJ4_last : kJ;
         const bool on2 = !last || on2_last, on4 = !last || on4_last;
@@ -561,10 +564,11 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
                     __builtin_fma(sixth_dt, __builtin_fma(2.0, f2.y, f1.y) + __builtin_fma(2.0, f3.y, f4.y), m.y),
                     __builtin_fma(sixth_dt, __builtin_fma(2.0, f2.z, f1.z) + __builtin_fma(2.0, f3.z, f4.z), m.z)};
         }
-        resets += simple_validate(mn, zr);                                 // simple_solver.py:168
-        fail |= zr;                                                        // robust_solver.py:192-205
-        m = mn;
-        if (RECORD) rec.put(i + 1, last ? T : mul_x((double)(i + 1), dt), m, 0.0);
+        const int rs = simple_validate(mn, zr);                            // simple_solver.py:168
+        resets += act ? rs : 0;
+        fail |= act && zr;                                                 // robust_solver.py:192-205
+        m = V3{act ? mn.x : m.x, act ? mn.y : m.y, act ? mn.z : m.z};
+        if (RECORD) { if (act) rec.put(i + 1, last ? T : mul_x((double)(i + 1), dt), m, 0.0); }
       }
       if (NSRC::kShared && !ns.chunk_end(i + 1 < n)) break;
     }
@@ -627,6 +631,15 @@ __device__ __forceinline__ double llgs_energy(const V3& m, const LlgsEnergyK& k)
 __device__ __forceinline__ double rms3(const V3& a) { return sqrt(dot(a, a)) / 1.7320508075688772; }   // common.py:63-65
 
 // A7 (+A8 when RECORD): scipy solve_ivp(RK45) as LLGSSolver.solve drives it.
+#ifdef STG_PROFILE_LOOP
+// experiment builds only (-DSTG_PROFILE_LOOP): cycles spent in the segments of the RK45 attempt, summed over the attempts
+// of wavefront 0 of workgroup 0, read back with stg_debug_prof()
+__device__ long long g_stg_prof[16];
+#define STG_TICK(k) do { const long long now_ = __builtin_readcyclecounter(); prof_[k] += now_ - last_; last_ = now_; } while (0)
+#else
+#define STG_TICK(k) do { } while (0)
+#endif
+
 template <bool THERMAL, bool RECORD, bool AXIS_Z, class NSRC>
 __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T, const LlgsK& k, double beta,
                                                double betap, double rtol, double atol, double max_step,
@@ -698,39 +711,53 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
     h_abs = h_abs > max_step ? max_step : (h_abs < min_step ? min_step : h_abs);          // rk.py:121-126
     // SharedNormals: the prologue's two RHS calls were chunk 0; every attempt is one further chunk and the loop is
     // wave-uniform (a finished lane idles until the wavefront's last lane is through)
+#ifdef STG_PROFILE_LOOP
+    long long prof_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long last_ = __builtin_readcyclecounter();
+#endif
     bool active = enabled && (t != T);       // (a disabled lane only walks the workgroup's chunk loop)
     bool wave_go = true;
     if (NSRC::kShared) wave_go = ns.chunk_end(active);
     if (wave_go)
     for (;;) {
-      if (!NSRC::kShared && !active) break;
-      if (active) {
-        if (h_abs < min_step || attempts >= max_attempts) { ok = false; active = false; }  // rk.py:132-133 (+ budget)
-      }
-      if (active) {
-        ++attempts;
+      // The loop is wave-uniform and its body has no lane-divergent control flow: a lane that is through (or never
+      // started) walks along with its state frozen by the selects below.  (The lane-divergent form -- break per lane,
+      // exec-masked body -- spent as long on its mask bookkeeping at the top of every iteration as on one RHS.)
+      const bool fail_now = active && (h_abs < min_step || attempts >= max_attempts);     // rk.py:132-133 (+ budget)
+      ok = ok && !fail_now;
+      active = active && !fail_now;
+      if (!NSRC::kShared && __ballot(active) == 0ull) break;
+      STG_TICK(0);
+      {
+        attempts += active ? 1 : 0;
         double t_new = add_x(t, h_abs);
         if (t_new - T > 0.0) t_new = T;
         const double h = sub_x(t_new, t);
-        h_abs = fabs(h);
+        const double h_try = fabs(h);
         // rk_step (rk.py:14-70); the one stage time that can pass T is formed without contraction
         const bool on_end = add_x(t, h) <= T;
         const V3 k1 = f;
         const V3 k2 = fun(V3{y.x + (k1.x * A21) * h, y.y + (k1.y * A21) * h, y.z + (k1.z * A21) * h}, true, true);
+        STG_TICK(1);
         const V3 k3 = fun(V3{y.x + (k1.x * A31 + k2.x * A32) * h, y.y + (k1.y * A31 + k2.y * A32) * h,
                              y.z + (k1.z * A31 + k2.z * A32) * h}, false, true);
+        STG_TICK(2);
         const V3 k4 = fun(V3{y.x + (k1.x * A41 + k2.x * A42 + k3.x * A43) * h, y.y + (k1.y * A41 + k2.y * A42 + k3.y * A43) * h,
                              y.z + (k1.z * A41 + k2.z * A42 + k3.z * A43) * h}, true, true);
+        STG_TICK(3);
         const V3 k5 = fun(V3{y.x + (k1.x * A51 + k2.x * A52 + k3.x * A53 + k4.x * A54) * h,
                              y.y + (k1.y * A51 + k2.y * A52 + k3.y * A53 + k4.y * A54) * h,
                              y.z + (k1.z * A51 + k2.z * A52 + k3.z * A53 + k4.z * A54) * h}, false, true);
+        STG_TICK(4);
         const V3 k6 = fun(V3{y.x + (k1.x * A61 + k2.x * A62 + k3.x * A63 + k4.x * A64 + k5.x * A65) * h,
                              y.y + (k1.y * A61 + k2.y * A62 + k3.y * A63 + k4.y * A64 + k5.y * A65) * h,
                              y.z + (k1.z * A61 + k2.z * A62 + k3.z * A63 + k4.z * A64 + k5.z * A65) * h}, true, on_end);
+        STG_TICK(5);
         const V3 y_new{y.x + h * (k1.x * B1 + k3.x * B3 + k4.x * B4 + k5.x * B5 + k6.x * B6),
                        y.y + h * (k1.y * B1 + k3.y * B3 + k4.y * B4 + k5.y * B5 + k6.y * B6),
                        y.z + h * (k1.z * B1 + k3.z * B3 + k4.z * B4 + k5.z * B5 + k6.z * B6)};
         const V3 f_new = fun(y_new, false, on_end);
+        STG_TICK(6);
         const V3 ev{(k1.x * E1 + k3.x * E3 + k4.x * E4 + k5.x * E5 + k6.x * E6 + f_new.x * E7) * h,
                     (k1.y * E1 + k3.y * E3 + k4.y * E4 + k5.y * E5 + k6.y * E6 + f_new.y * E7) * h,
                     (k1.z * E1 + k3.z * E3 + k4.z * E4 + k5.z * E5 + k6.z * E6 + f_new.z * E7) * h};
@@ -744,25 +771,32 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
         // Controller (rk.py:158-181), branch-free: both outcomes share err^-0.2 and differ in a handful of selects.
         // 0.9 * err^-0.2 saturates at MAX_FACTOR = 10 for err <= 0.09^5 and at MIN_FACTOR = 0.2 for err >= 4.5^5 (err is
         // the SQUARED norm here); NaN error norms reject (nan < 1 is False) with fmax(0.2, NaN) = 0.2, as in SciPy.
-        const bool acc = err < 1.0;
+        const bool acc = active && err < 1.0;
         const double r9 = 0.9 * inv_tenth_root(err);
         double fa = (err <= 3.486784401e-11) ? 10.0 : fmin(10.0, r9);                      // also err == 0
         fa = rejected ? fmin(1.0, fa) : fa;
         const double fr = (err >= 3405062.8916015625) ? 0.2 : fmax(0.2, r9);
-        h_abs *= acc ? fa : fr;
+        h_abs = active ? h_try * (acc ? fa : fr) : h_abs;
         // an accepted attempt advances, records, and does the next step()'s prologue
         t = acc ? t_new : t;
         y = V3{acc ? y_new.x : y.x, acc ? y_new.y : y.y, acc ? y_new.z : y.z};
         f = V3{acc ? f_new.x : f.x, acc ? f_new.y : f.y, acc ? f_new.z : f.z};
         if (RECORD) { if (acc) emit(); } else npts += acc ? 1 : 0;
-        rejected = !acc;
+        rejected = active ? !acc : rejected;
         min_step = min_step_at(t);                                                         // unchanged t -> unchanged value
         const double hc = h_abs > max_step ? max_step : (h_abs < min_step ? min_step : h_abs);
         h_abs = acc ? hc : h_abs;
-        active = (t != T);
+        active = active && (t != T);
+        STG_TICK(7);
       }
       if (NSRC::kShared && !ns.chunk_end(active)) break;
     }
+#ifdef STG_PROFILE_LOOP
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int j = 0; j < 10; ++j) g_stg_prof[j] = prof_[j];
+        g_stg_prof[10] = attempts;
+    }
+#endif
     if (!RECORD) { emit(); --npts; }
     o.n = npts - 1;
     o.work = attempts;
