@@ -57,7 +57,7 @@ def parse_args():
     ap.add_argument("--lane-sort", default="auto", choices=["auto", "on", "off"],
                     help="duration-sorted lane schedule (auto = on)")
     ap.add_argument("--wave-spec", default="auto", choices=["auto", "on", "off"],
-                    help="producer/consumer wavefront pairs for the thermal kernels (auto = on up to 131072 envs)")
+                    help="producer/consumer wavefront pairs for the thermal kernels (auto = on up to 65536 envs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank code path on a single GPU)")
     return ap.parse_args()

@@ -94,7 +94,9 @@ typedef struct {
                                        H_k from VCMAMRAMDevice._compute_effective_anisotropy (vcma_mram.py:122-147)
                                        at V = J R(m) A while the pulse is on.  The reference env never calls these
                                        formulas; the model is pinned against the device classes, not against env runs. */
-    int32_t wave_spec;               /* thermal kernels: producer/consumer wavefront pairs. 0 auto, 1 always, -1 never */
+    int32_t wave_spec;              /* thermal kernels: every integrating wavefront gets a second wavefront that runs the
+                                       envs' normal streams ahead into LDS (same values, same order: results are
+                                       bit-identical).  0 = automatic (launches of <= 65536 envs), 1 always, -1 never */
     int32_t lane_sort;              /* schedule of envs onto lanes: 0 = automatic (sort), 1 = always sort the envs by pulse duration
                                        on the device before each step so that the lanes of a wavefront have equal trip
                                        counts, -1 = identity.  Results are unaffected: an env's arithmetic does not depend
