@@ -935,3 +935,48 @@ def test_randomised_configurations_vs_oracle(stg, solver):
         tol = (TOL_RK45 if solver == "rk45" else TOL_RK4) * (50 if thermal else 1)       # normals carry fp32 device transcendentals
         worst = max(worst, _compare(outs, tol))
     print(solver, "randomised configurations: worst |dm| =", worst)
+
+
+def test_c_abi_error_behaviour(stg):
+    """Every entry point returns a negative STG_E_* code with a message instead of faulting: wrong call order, NULL
+    pointers, invalid sizes and configurations (the reference's step() never raises for bad actions either, but its
+    constructors do for bad configurations)."""
+    import ctypes as C
+    from spin_torque_gym_amd import _lib
+    from spin_torque_gym_amd.backend import EnvConfig
+    lib = _lib.load()
+    cfg = EnvConfig(solver="rk4").to_abi()
+    ctx = C.c_void_p()
+    assert lib.stg_create(C.byref(ctx), 0, 0, 0, C.byref(cfg)) < 0 and b"n_envs" in lib.stg_last_error()
+    assert lib.stg_create(C.byref(ctx), 99, 64, 0, C.byref(cfg)) < 0
+    bad = EnvConfig(solver="rk4").to_abi(); bad.max_step = 0.0
+    assert lib.stg_create(C.byref(ctx), 0, 64, 0, C.byref(bad)) < 0
+    bad = EnvConfig(solver="rk45").to_abi(); bad.noise_model = 1
+    assert lib.stg_create(C.byref(ctx), 0, 64, 0, C.byref(bad)) < 0 and b"fixed-step" in lib.stg_last_error()
+    assert lib.stg_create(C.byref(ctx), 0, 64, 0, C.byref(cfg)) == 0
+    n = 64
+    dev = torch.device("cuda", 0)
+    obs = torch.empty((12, n), dtype=torch.float32, device=dev)
+    rew = torch.empty(n, dtype=torch.float32, device=dev)
+    te = torch.empty(n, dtype=torch.uint8, device=dev); tr = torch.empty_like(te)
+    act = torch.zeros((2, n), dtype=torch.float32, device=dev); act[1] = 1e-10
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    # order: params -> reset -> step
+    assert lib.stg_reset(ctx, None, None, None, C.c_uint64(0), ptr(obs), None) < 0
+    assert lib.stg_step(ctx, ptr(act), 0, ptr(obs), ptr(rew), None, None, ptr(te), ptr(tr), None, None) < 0
+    p = stg.devices.flatten_params(stg.DeviceFactory().create_device("stt_mram", stt_default_params()))
+    assert lib.stg_set_params(ctx, C.byref(p), 0, None) < 0                       # no classes
+    assert lib.stg_set_params(ctx, C.byref(p), 2, None) < 0                       # two classes need a class index
+    assert lib.stg_set_params(ctx, C.byref(p), 1, None) == 0
+    assert lib.stg_step(ctx, ptr(act), 0, ptr(obs), ptr(rew), None, None, ptr(te), ptr(tr), None, None) < 0   # no reset yet
+    assert lib.stg_reset(ctx, None, None, None, C.c_uint64(0), ptr(obs), None) == 0
+    assert lib.stg_step(ctx, None, 0, ptr(obs), ptr(rew), None, None, ptr(te), ptr(tr), None, None) < 0       # NULL actions
+    assert lib.stg_step_many(ctx, 0, ptr(act), 0, 1, 0, ptr(obs), None, ptr(rew), None, None, ptr(te), ptr(tr), None, None) < 0
+    assert lib.stg_step(ctx, ptr(act), 0, ptr(obs), ptr(rew), None, None, ptr(te), ptr(tr), None, None) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(obs).all()
+    out = (C.c_uint64 * 4)()
+    assert lib.stg_get_counters(ctx, out, 0) == 0 and out[0] == n
+    assert lib.stg_get_counters(None, out, 0) < 0 and lib.stg_thermal_strength(ctx, 5, C.byref(C.c_double())) < 0
+    lib.stg_destroy(ctx)
+    lib.stg_destroy(None)                                                          # a no-op, like free(NULL)
