@@ -157,6 +157,18 @@ int stg_set_params(stg_ctx* ctx, const stg_device_params* table, int32_t n_class
 
 /* ---- env level ---------------------------------------------------------------------------------------- */
 
+/* Per-env parameters (SURVEY 8b `stg_set_params_per_env`; domain randomisation / device-to-device variation): instead of
+ * a class table, every env carries its own parameter record.  soa_params is a DEVICE array [STG_NPARAM][N] of doubles
+ * whose rows are the double-valued fields of stg_device_params in declaration order (damping, ms, ku, volume,
+ * polarization, easy_axis[3], demag[3], a_ex, area, r_p, r_ap, ref_m[3], r_series, sot_tau_dl, sot_tau_fl,
+ * sot_sigma[3], vcma_xi, vcma_td, vcma_vbd, shape_demag[3]); dev_type and params_valid are DEVICE arrays uint8[N]
+ * (STG_DEV_*; the host-evaluated outcome of utils/validation.py:176-234 per env).  The library copies all three.
+ * Each lane derives its constants in the kernel prologue with the same arithmetic the host uses for a class table, so
+ * an env gives bit-identical results either way.  Replaces a previous stg_set_params (and vice versa); stg_solve*,
+ * stg_device_terms and stg_thermal_strength work on class tables only. */
+#define STG_NPARAM 30
+int stg_set_params_per_env(stg_ctx* ctx, const double* soa_params, const uint8_t* dev_type, const uint8_t* params_valid);
+
 /* SpinTorqueEnv.reset (spin_torque_env.py:250-308) for the envs with mask[i] != 0 (mask NULL: all).
  * init_m / target [dev] double[3][N]: options['initial_state'] / options['target_state'] (normalised by the kernel as
  * device.validate_magnetization does); NULL: drawn on the device (normal(0,1,3) normalised; uniform choice among

@@ -42,6 +42,15 @@ struct CfgView {
     int32_t max_steps, n_targets, skip_done;
 };
 
+// Per-env parameter block (stg_set_params_per_env): STG_NPARAM rows of N doubles in the field order of
+// stg_device_params, plus the device type and the host-evaluated validity flag per env.
+struct EnvParams {
+    const double* soa;        // [STG_NPARAM][N] or nullptr
+    const uint8_t* type;      // [N]
+    const uint8_t* valid;     // [N]
+    double gamma, temperature;
+};
+
 struct StepArgs {
     StateView s;
     CfgView c;
@@ -49,6 +58,8 @@ struct StepArgs {
     const double* ctab;
     const uint8_t* cls;
     int32_t ncls;
+    EnvParams ep;                 // per-env parameters (soa == nullptr: class table)
+    int32_t force_wg1;
     const void* actions;          // [K][2][N]
     int32_t K, out_every, autoreset;
     const uint32_t* perm;         // lane -> env (duration-sorted schedule) or nullptr
@@ -78,12 +89,41 @@ struct SolveArgs {
 // ------------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------------
-// Stages the class table in LDS (MULTI) and returns this lane's row.  With a single class the row is read
-// straight from the (wave-uniform) global pointer, which the compiler turns into scalar loads.
+__device__ __forceinline__ void load_env_params(const EnvParams& e, int64_t N, int64_t i, stg_device_params& p) {
+    const double* q = e.soa + i;
+    int r = 0;
+    auto nx = [&]() { const double v = q[(int64_t)r * N]; ++r; return v; };
+    p.damping = nx(); p.ms = nx(); p.ku = nx(); p.volume = nx(); p.polarization = nx();
+    for (int k = 0; k < 3; ++k) p.easy_axis[k] = nx();
+    for (int k = 0; k < 3; ++k) p.demag[k] = nx();
+    p.a_ex = nx(); p.area = nx(); p.r_p = nx(); p.r_ap = nx();
+    for (int k = 0; k < 3; ++k) p.ref_m[k] = nx();
+    p.r_series = nx(); p.sot_tau_dl = nx(); p.sot_tau_fl = nx();
+    for (int k = 0; k < 3; ++k) p.sot_sigma[k] = nx();
+    p.vcma_xi = nx(); p.vcma_td = nx(); p.vcma_vbd = nx();
+    for (int k = 0; k < 3; ++k) p.shape_demag[k] = nx();
+    p.dev_type = (int32_t)e.type[i];
+    p.params_valid = (int32_t)e.valid[i];
+}
+
+// Returns this lane's row of derived constants.  One class: the (wave-uniform) global table row, which the compiler
+// turns into scalar loads.  MULTI: the class table staged in LDS, or -- per-env parameters -- a row per lane derived
+// here from the env's own record (the LDS block holds exactly 64 rows: per-env launches use 64 integrating lanes per
+// workgroup; lanes of a producer wavefront read the row of the integrating lane they mirror).
 template <bool MULTI>
 __device__ __forceinline__ const double* class_row(const double* ctab, const uint8_t* cls, int32_t ncls, int64_t i,
-                                                   bool in_range, double* lds) {
+                                                   bool in_range, double* lds, const EnvParams& ep, int64_t N) {
     if (MULTI) {
+        if (ep.soa) {
+            const int lane = (int)(threadIdx.x & 63u);
+            if (threadIdx.x < 64 && in_range) {
+                stg_device_params p;
+                load_env_params(ep, N, i, p);
+                derive_row(p, ep.gamma, ep.temperature, lds + lane * C_COUNT);
+            }
+            __syncthreads();
+            return lds + lane * C_COUNT;
+        }
         for (int j = threadIdx.x; j < ncls * C_COUNT; j += blockDim.x) lds[j] = ctab[j];
         __syncthreads();
         const int c = in_range ? (int)cls[i] : 0;
@@ -287,7 +327,7 @@ __global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR st
     // duration-sorted schedule: slot j of the launch integrates env perm[j], so the 64 lanes of a wavefront have
     // (nearly) equal trip counts; all state and outputs stay at the env's own index
     const int64_t i = live ? (a.perm ? (int64_t)a.perm[lane_slot] : lane_slot) : 0;
-    const double* row = class_row<MULTI>(a.ctab, a.cls, a.ncls, i, live, s_tab);
+    const double* row = class_row<MULTI>(a.ctab, a.cls, a.ncls, i, live, s_tab, a.ep, a.N);
     // Lanes without an env: the one-wavefront form has no rendezvous after this point and lets them go; in the
     // wave-specialised form they stay (inert) because every wavefront of the workgroup takes part in every s_barrier.
     if (!PC && !live) return;
@@ -430,7 +470,7 @@ __global__ void __launch_bounds__(64) stg_solve_kernel(const SolveArgs a) {
     __shared__ double s_tab[MULTI ? STG_MAX_CLASSES * C_COUNT : 1];
     const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool in_range = i < a.N;
-    const double* row = class_row<MULTI>(a.ctab, a.cls, a.ncls, i, in_range, s_tab);
+    const double* row = class_row<MULTI>(a.ctab, a.cls, a.ncls, i, in_range, s_tab, EnvParams{}, a.N);
     if (!in_range) return;
     const int64_t N = a.N;
     const V3 m0{a.m0[i], a.m0[N + i], a.m0[2 * N + i]};
@@ -457,13 +497,14 @@ struct ResetArgs {
     const double *init_m, *target;
     uint64_t seed;
     float* obs;
+    EnvParams ep;
 };
 
 __global__ void __launch_bounds__(64) stg_reset_kernel(const ResetArgs a) {
     __shared__ double s_tab[STG_MAX_CLASSES * C_COUNT];
     const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool in_range = i < a.N;
-    const double* row = (a.ncls > 1) ? class_row<true>(a.ctab, a.cls, a.ncls, i, in_range, s_tab) : a.ctab;
+    const double* row = (a.ncls > 1 || a.ep.soa) ? class_row<true>(a.ctab, a.cls, a.ncls, i, in_range, s_tab, a.ep, a.N) : a.ctab;
     if (!in_range) return;
     const int64_t N = a.N;
     if (a.mask && !a.mask[i]) {
@@ -528,6 +569,7 @@ struct PlanArgs {
     int32_t skip_done;
     const uint8_t* cls;       // device-physics torque model with several classes: group lanes by device kind
     const double* ctab;
+    const uint8_t* env_type;  // (per-env parameters: the kind of each env)
     int32_t by_kind;
     uint32_t* perm;
 };
@@ -540,7 +582,7 @@ __device__ __forceinline__ int plan_key(const PlanArgs& a, int64_t i) {
     const double w = fmax(T, 1e-10) / a.max_duration;          // below 0.1 ns the RK4 sub-step count stays at ~100
     int b = (int)(w * (PLAN_DUR - 1));
     b = b < 0 ? 0 : (b > PLAN_DUR - 2 ? PLAN_DUR - 2 : b);
-    const int kind = a.by_kind ? (int)a.ctab[(int)a.cls[i] * C_COUNT + C_DEVTYPE] : 0;
+    const int kind = a.by_kind ? (a.env_type ? (int)a.env_type[i] : (int)a.ctab[(int)a.cls[i] * C_COUNT + C_DEVTYPE]) : 0;
     return kind * PLAN_DUR + (PLAN_DUR - 2) - b;               // descending work inside each kind: long pulses first
 }
 
@@ -634,7 +676,18 @@ struct stg_ctx {
     bool have_params = false, have_state = false;
     bool axis_z = false;              // every class has easy axis = +z exactly: the specialised Simple RHS applies
     bool axis_z_llgs = false;         // every class has raw easy axis (0,0,rz) and demag (0,0,Nz): specialised LLGS RHS
+    // per-env parameters (stg_set_params_per_env): library-owned copies
+    double* env_soa = nullptr;        // [STG_NPARAM][N]
+    uint8_t *env_type = nullptr, *env_valid = nullptr;
+    bool per_env = false;
 };
+
+static EnvParams env_params_of(const stg_ctx* ctx) {
+    EnvParams e{};
+    if (ctx->per_env) { e.soa = ctx->env_soa; e.type = ctx->env_type; e.valid = ctx->env_valid; }
+    e.gamma = ctx->cfg.gamma; e.temperature = ctx->cfg.temperature;
+    return e;
+}
 
 static CfgView cfg_view(const stg_config& c) {
     CfgView v{};
@@ -713,45 +766,13 @@ void stg_destroy(stg_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->slab) (void)hipFree(ctx->slab);
+    if (ctx->env_soa) (void)hipFree(ctx->env_soa);
+    if (ctx->env_type) (void)hipFree(ctx->env_type);
     delete ctx;
 }
 
-// Derived constants, in the reference's own operation order (each line cites the expression it evaluates).
 static void derive_class(const stg_device_params& p, const stg_config& cfg, double* r) {
-    const double mu0 = 4 * M_PI * 1e-7;                                          // simple_solver.py:60
-    const double en = std::sqrt((p.easy_axis[0] * p.easy_axis[0] + p.easy_axis[1] * p.easy_axis[1]) + p.easy_axis[2] * p.easy_axis[2]);
-    r[C_EX] = p.easy_axis[0] / en; r[C_EY] = p.easy_axis[1] / en; r[C_EZ] = p.easy_axis[2] / en;   // simple_solver.py:318
-    r[C_HK] = (2 * p.ku) / (mu0 * p.ms);                                         // simple_solver.py:370 == llgs_solver.py:196
-    r[C_MS] = p.ms;
-    r[C_ALPHA] = p.damping;
-    r[C_GEFF] = cfg.gamma / (1 + p.damping * p.damping);                         // simple_solver.py:337
-    r[C_POL] = p.polarization;
-    r[C_MSV] = p.ms * p.volume;                                                  // simple_solver.py:330
-    r[C_HS_SIMPLE] = std::sqrt(2 * p.damping * 1.38e-23 * cfg.temperature / (mu0 * p.ms * p.volume * cfg.gamma));   // :380-383
-    r[C_RX] = p.easy_axis[0]; r[C_RY] = p.easy_axis[1]; r[C_RZ] = p.easy_axis[2];
-    r[C_DX] = -p.ms * p.demag[0]; r[C_DY] = -p.ms * p.demag[1]; r[C_DZ] = -p.ms * p.demag[2];   // llgs_solver.py:201
-    r[C_HEX] = p.a_ex > 0 ? (2 * p.a_ex / (mu0 * p.ms)) * 0.1 : 0.0;             // llgs_solver.py:205-209
-    r[C_BETA] = p.polarization * cfg.gamma / (2 * p.ms * p.volume);              // llgs_solver.py:229
-    r[C_BETAP] = 0.1 * r[C_BETA];                                                // llgs_solver.py:230
-    r[C_GAMMA] = cfg.gamma;
-    r[C_HS_LLGS] = std::sqrt(2 * p.damping * 1.380649e-23 * cfg.temperature / (cfg.gamma * mu0 * p.ms * p.volume));  // llgs_solver.py:87-90
-    r[C_KUV] = p.ku * p.volume;                                                  // llgs_solver.py:256
-    r[C_EDEMAG] = 0.5 * mu0 * (p.ms * p.ms) * p.volume;                          // llgs_solver.py:260
-    r[C_NX] = p.demag[0]; r[C_NY] = p.demag[1]; r[C_NZ] = p.demag[2];
-    r[C_AREA] = p.area; r[C_RP] = p.r_p; r[C_RAP] = p.r_ap;
-    r[C_TMR] = (p.r_ap - p.r_p) / p.r_p;                                         // stt_mram.py:88
-    const double rn = std::sqrt((p.ref_m[0] * p.ref_m[0] + p.ref_m[1] * p.ref_m[1]) + p.ref_m[2] * p.ref_m[2]);
-    r[C_REFX] = p.ref_m[0] / rn; r[C_REFY] = p.ref_m[1] / rn; r[C_REFZ] = p.ref_m[2] / rn;
-    r[C_RSERIES] = p.r_series;
-    r[C_DEVTYPE] = (double)p.dev_type;
-    r[C_VALID] = p.params_valid ? 1.0 : 0.0;
-    r[C_SOT_DL] = p.sot_tau_dl; r[C_SOT_FL] = p.sot_tau_fl;
-    r[C_SIGX] = p.sot_sigma[0]; r[C_SIGY] = p.sot_sigma[1]; r[C_SIGZ] = p.sot_sigma[2];
-    r[C_KU] = p.ku;
-    r[C_VCMA_XI] = p.vcma_xi;
-    r[C_VCMA_TD2] = p.vcma_td * p.vcma_td;                                       // dielectric_thickness**2, vcma_mram.py:139
-    r[C_VCMA_VBD] = p.vcma_vbd;
-    r[C_MU0MS] = mu0 * p.ms;
+    derive_row(p, cfg.gamma, cfg.temperature, r);      // stg_physics.hpp (shared with the per-env device path)
 }
 
 int stg_set_params(stg_ctx* ctx, const stg_device_params* table, int32_t n_classes, const uint8_t* cls) {
@@ -778,6 +799,47 @@ int stg_set_params(stg_ctx* ctx, const stg_device_params* table, int32_t n_class
         ctx->axis_z_llgs = ctx->axis_z_llgs && r[C_RX] == 0.0 && r[C_RY] == 0.0 && r[C_DX] == 0.0 && r[C_DY] == 0.0;
     }
     ctx->cls = n_classes > 1 ? cls : nullptr;
+    ctx->per_env = false;
+    ctx->have_params = true;
+    return STG_OK;
+}
+
+// axis flags of a per-env parameter block: flag[0] = some env's easy axis is not exactly +z after normalisation,
+// flag[1] = some env's raw axis or demag factors have x/y components (LLGS specialisation)
+__global__ void stg_env_axis_kernel(const double* soa, int64_t N, int32_t* flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double ex = soa[5 * N + i], ey = soa[6 * N + i], ez = soa[7 * N + i];
+    const double dx = soa[8 * N + i], dy = soa[9 * N + i];
+    const double en = sqrt((ex * ex + ey * ey) + ez * ez);
+    if (!(ex / en == 0.0 && ey / en == 0.0 && ez / en == 1.0)) flag[0] = 1;
+    if (!(ex == 0.0 && ey == 0.0 && -dx == 0.0 && -dy == 0.0)) flag[1] = 1;
+}
+
+int stg_set_params_per_env(stg_ctx* ctx, const double* soa_params, const uint8_t* dev_type, const uint8_t* params_valid) {
+    if (!ctx || !soa_params || !dev_type || !params_valid) return fail(STG_E_INVALID, "ctx/soa_params/dev_type/params_valid is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t N = (size_t)ctx->N;
+    if (!ctx->env_soa) {
+        HIP_TRY(hipMalloc(&ctx->env_soa, sizeof(double) * STG_NPARAM * N));
+        HIP_TRY(hipMalloc(&ctx->env_type, 2 * N));
+        ctx->env_valid = ctx->env_type + N;
+    }
+    HIP_TRY(hipMemcpy(ctx->env_soa, soa_params, sizeof(double) * STG_NPARAM * N, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy(ctx->env_type, dev_type, N, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy(ctx->env_valid, params_valid, N, hipMemcpyDeviceToDevice));
+    // the specialised right-hand sides apply only if EVERY env has the default axis geometry
+    int32_t h_flag[2] = {0, 0};
+    int32_t* d_flag = nullptr;
+    HIP_TRY(hipMalloc(&d_flag, 8));
+    HIP_TRY(hipMemset(d_flag, 0, 8));
+    hipLaunchKernelGGL(stg_env_axis_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, ctx->env_soa, (int64_t)N, d_flag);
+    HIP_TRY(hipMemcpy(h_flag, d_flag, 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d_flag);
+    ctx->axis_z = h_flag[0] == 0;
+    ctx->axis_z_llgs = h_flag[1] == 0;
+    ctx->ncls = 0; ctx->cls = nullptr;
+    ctx->per_env = true;
     ctx->have_params = true;
     return STG_OK;
 }
@@ -785,6 +847,7 @@ int stg_set_params(stg_ctx* ctx, const stg_device_params* table, int32_t n_class
 int stg_thermal_strength(stg_ctx* ctx, int32_t cls, double* out) {
     if (!ctx || !out) return fail(STG_E_INVALID, "ctx/out is NULL");
     if (!ctx->have_params) return fail(STG_E_STATE, "stg_set_params has not been called");
+    if (ctx->per_env) return fail(STG_E_STATE, "per-env parameters have no class table");
     if (cls < 0 || cls >= ctx->ncls) return fail(STG_E_INVALID, "cls out of range");
     *out = ctx->h_ctab[cls][ctx->cfg.solver == STG_SOLVER_RK45 ? C_HS_LLGS : C_HS_SIMPLE];
     return STG_OK;
@@ -803,7 +866,7 @@ int stg_reset(stg_ctx* ctx, const uint8_t* mask, const double* init_m, const dou
     HIP_TRY(hipSetDevice(ctx->device));
     ResetArgs a{};
     a.s = ctx->s; a.c = cfg_view(ctx->cfg); a.N = ctx->N; a.env_id0 = ctx->env_id0;
-    a.ctab = ctx->ctab; a.cls = ctx->cls; a.ncls = ctx->ncls;
+    a.ctab = ctx->ctab; a.cls = ctx->cls; a.ncls = ctx->ncls; a.ep = env_params_of(ctx);
     a.mask = mask; a.init_m = init_m; a.target = target; a.seed = seed; a.obs = obs_out;
     hipLaunchKernelGGL(stg_reset_kernel, grid_for(ctx->N), dim3(64), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
@@ -837,7 +900,7 @@ static void launch_step(const StepArgs& a, int act_f64, bool pc, hipStream_t st)
         return;
     }
     // workgroups of 4 integrating wavefronts once there is one per CU, of 1 below that
-    if (a.N >= STG_WG4_MIN_ENVS) launch_step_w<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, 4>(a, act_f64, pc, st);
+    if (a.N >= STG_WG4_MIN_ENVS && !a.force_wg1) launch_step_w<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, 4>(a, act_f64, pc, st);
     else launch_step_w<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, 1>(a, act_f64, pc, st);
 }
 template <int SOLVER, bool AXIS_Z, bool DEVPHYS>
@@ -869,7 +932,7 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
     HIP_TRY(hipSetDevice(ctx->device));
     StepArgs a{};
     a.s = ctx->s; a.c = cfg_view(ctx->cfg); a.N = ctx->N; a.env_id0 = ctx->env_id0;
-    a.ctab = ctx->ctab; a.cls = ctx->cls; a.ncls = ctx->ncls;
+    a.ctab = ctx->ctab; a.cls = ctx->cls; a.ncls = ctx->ncls; a.ep = env_params_of(ctx);
     a.counters = ctx->counters;
     hipStream_t st = (hipStream_t)stream;
     a.perm = nullptr;
@@ -884,7 +947,8 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
         pa.done = ctx->s.done; pa.skip_done = (ctx->cfg.skip_done && !autoreset) ? 1 : 0;
         pa.perm = ctx->perm;
         pa.cls = ctx->cls; pa.ctab = ctx->ctab;
-        pa.by_kind = (ctx->cfg.torque_model == 1 && ctx->ncls > 1 && ctx->cls) ? 1 : 0;
+        pa.env_type = ctx->per_env ? ctx->env_type : nullptr;
+        pa.by_kind = (ctx->cfg.torque_model == 1 && ((ctx->ncls > 1 && ctx->cls) || ctx->per_env)) ? 1 : 0;
         const dim3 g((unsigned)((ctx->N + TILE_ENVS - 1) / TILE_ENVS));
         hipLaunchKernelGGL(stg_plan_tile_kernel, g, dim3(PLAN_THREADS), 0, st, pa);
         a.perm = ctx->perm;
@@ -893,8 +957,9 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
     a.obs = obs; a.final_obs = final_obs; a.reward = reward; a.reward64 = reward_f64; a.energy = energy; a.term = terminated; a.trunc = truncated; a.status = status;
     // the Simple solver only draws a thermal field when temperature > 0 (simple_solver.py:321,378)
     const bool thermal = ctx->cfg.thermal && ctx->cfg.temperature > 0;
-    const bool multi = ctx->ncls > 1;
+    const bool multi = ctx->ncls > 1 || ctx->per_env;
     const bool devphys = ctx->cfg.torque_model == 1;
+    a.force_wg1 = ctx->per_env ? 1 : 0;       // per-env rows fill the 64-row LDS block: 64 integrating lanes per workgroup
     // wave_spec: 0 = automatic (thermal launches of at most STG_WAVE_SPEC_MAX_ENVS envs, i.e. latency-bound ones),
     // 1 = always, -1 = never.  Results do not depend on it.
     const bool pc = ctx->cfg.wave_spec > 0 || (ctx->cfg.wave_spec == 0 && ctx->N <= STG_WAVE_SPEC_MAX_ENVS);
@@ -932,6 +997,7 @@ static int solve_common(stg_ctx* ctx, const double* m0, const double* J, const d
                         uint8_t* success, void* stream, bool record) {
     if (!ctx) return fail(STG_E_INVALID, "ctx is NULL");
     if (!ctx->have_params) return fail(STG_E_STATE, "stg_set_params must precede stg_solve");
+    if (ctx->per_env) return fail(STG_E_STATE, "stg_solve* works on the class table (stg_set_params), not on per-env parameters");
     if (!m0 || !J || !T || !m_final) return fail(STG_E_INVALID, "m0/J/T/m_final must not be NULL");
     if (record && traj_cap < 1) return fail(STG_E_INVALID, "traj_cap must be >= 1");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1020,6 +1086,7 @@ int stg_device_terms(stg_ctx* ctx, const double* m, const double* J, const doubl
                      double* k_eff, void* stream) {
     if (!ctx) return fail(STG_E_INVALID, "ctx is NULL");
     if (!ctx->have_params) return fail(STG_E_STATE, "stg_set_params must precede stg_device_terms");
+    if (ctx->per_env) return fail(STG_E_STATE, "stg_device_terms works on the class table (stg_set_params), not on per-env parameters");
     if ((tau_dl || tau_fl) && (!m || !J)) return fail(STG_E_INVALID, "m and J are required for the SOT torques");
     if (k_eff && !volt) return fail(STG_E_INVALID, "volt is required for K_eff");
     HIP_TRY(hipSetDevice(ctx->device));

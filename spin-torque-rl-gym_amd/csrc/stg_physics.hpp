@@ -63,6 +63,48 @@ enum ClassConst : int {
     C_COUNT
 };
 
+// Derived constants of one device-parameter record, in the reference's own operation order (each line cites the
+// expression it evaluates).  Host: stg_set_params builds the class table with it; device: per-env parameters
+// (stg_set_params_per_env) are derived by each lane in the kernel prologue -- same arithmetic, no contraction.
+template <class P>
+__host__ __device__ inline void derive_row(const P& p, double gamma, double temperature, double* r) {
+#pragma clang fp contract(off)
+    const double mu0 = 4 * 3.14159265358979323846 * 1e-7;                        // simple_solver.py:60
+    const double en = sqrt((p.easy_axis[0] * p.easy_axis[0] + p.easy_axis[1] * p.easy_axis[1]) + p.easy_axis[2] * p.easy_axis[2]);
+    r[C_EX] = p.easy_axis[0] / en; r[C_EY] = p.easy_axis[1] / en; r[C_EZ] = p.easy_axis[2] / en;   // simple_solver.py:318
+    r[C_HK] = (2 * p.ku) / (mu0 * p.ms);                                         // simple_solver.py:370 == llgs_solver.py:196
+    r[C_MS] = p.ms;
+    r[C_ALPHA] = p.damping;
+    r[C_GEFF] = gamma / (1 + p.damping * p.damping);                             // simple_solver.py:337
+    r[C_POL] = p.polarization;
+    r[C_MSV] = p.ms * p.volume;                                                  // simple_solver.py:330
+    r[C_HS_SIMPLE] = sqrt(2 * p.damping * 1.38e-23 * temperature / (mu0 * p.ms * p.volume * gamma));   // :380-383
+    r[C_RX] = p.easy_axis[0]; r[C_RY] = p.easy_axis[1]; r[C_RZ] = p.easy_axis[2];
+    r[C_DX] = -p.ms * p.demag[0]; r[C_DY] = -p.ms * p.demag[1]; r[C_DZ] = -p.ms * p.demag[2];   // llgs_solver.py:201
+    r[C_HEX] = p.a_ex > 0 ? (2 * p.a_ex / (mu0 * p.ms)) * 0.1 : 0.0;             // llgs_solver.py:205-209
+    r[C_BETA] = p.polarization * gamma / (2 * p.ms * p.volume);                  // llgs_solver.py:229
+    r[C_BETAP] = 0.1 * r[C_BETA];                                                // llgs_solver.py:230
+    r[C_GAMMA] = gamma;
+    r[C_HS_LLGS] = sqrt(2 * p.damping * 1.380649e-23 * temperature / (gamma * mu0 * p.ms * p.volume));  // llgs_solver.py:87-90
+    r[C_KUV] = p.ku * p.volume;                                                  // llgs_solver.py:256
+    r[C_EDEMAG] = 0.5 * mu0 * (p.ms * p.ms) * p.volume;                          // llgs_solver.py:260
+    r[C_NX] = p.demag[0]; r[C_NY] = p.demag[1]; r[C_NZ] = p.demag[2];
+    r[C_AREA] = p.area; r[C_RP] = p.r_p; r[C_RAP] = p.r_ap;
+    r[C_TMR] = (p.r_ap - p.r_p) / p.r_p;                                         // stt_mram.py:88
+    const double rn = sqrt((p.ref_m[0] * p.ref_m[0] + p.ref_m[1] * p.ref_m[1]) + p.ref_m[2] * p.ref_m[2]);
+    r[C_REFX] = p.ref_m[0] / rn; r[C_REFY] = p.ref_m[1] / rn; r[C_REFZ] = p.ref_m[2] / rn;
+    r[C_RSERIES] = p.r_series;
+    r[C_DEVTYPE] = (double)p.dev_type;
+    r[C_VALID] = p.params_valid ? 1.0 : 0.0;
+    r[C_SOT_DL] = p.sot_tau_dl; r[C_SOT_FL] = p.sot_tau_fl;
+    r[C_SIGX] = p.sot_sigma[0]; r[C_SIGY] = p.sot_sigma[1]; r[C_SIGZ] = p.sot_sigma[2];
+    r[C_KU] = p.ku;
+    r[C_VCMA_XI] = p.vcma_xi;
+    r[C_VCMA_TD2] = p.vcma_td * p.vcma_td;                                       // dielectric_thickness**2, vcma_mram.py:139
+    r[C_VCMA_VBD] = p.vcma_vbd;
+    r[C_MU0MS] = mu0 * p.ms;
+}
+
 struct V3 {
     double x, y, z;
 };

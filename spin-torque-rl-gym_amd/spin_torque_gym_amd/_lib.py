@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("STG_HIP_LIBRARY") or os.path.join(_HERE, "libspintorq
 
 STG_MAX_TARGETS = 8
 STG_MAX_CLASSES = 64
+STG_NPARAM = 30          # double-valued fields of stg_device_params, in declaration order
 SOLVERS = {"rk4": 0, "euler": 1, "rk45": 2}
 DEV_TYPES = {"stt_mram": 0, "sot_mram": 1, "vcma_mram": 2}
 STATUS_OK, STATUS_NOOP, STATUS_RESET, STATUS_INACTIVE = 0, 1, 2, 3
@@ -56,6 +57,7 @@ SYMBOLS = {
     "stg_last_error": (C.c_char_p, []),
     "stg_abi_version": (C.c_int, []),
     "stg_set_params": (C.c_int, [_VP, C.POINTER(StgDeviceParams), C.c_int32, _VP]),
+    "stg_set_params_per_env": (C.c_int, [_VP, _VP, _VP, _VP]),
     "stg_reset": (C.c_int, [_VP, _VP, _VP, _VP, C.c_uint64, _VP, _VP]),
     "stg_step": (C.c_int, [_VP, _VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "stg_step_many": (C.c_int, [_VP, C.c_int32, _VP, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),

@@ -155,6 +155,17 @@ class HipBackend:
         _lib.check(self.lib.stg_set_params(self._ctx, arr, len(table), _ptr(self._cls)))
         self.n_classes = len(table)
 
+    def set_params_per_env(self, block, dev_type, valid):
+        """Per-env parameters: block float64 [STG_NPARAM, N] (rows = the double fields of stg_device_params in
+        declaration order, see devices.PARAM_ROWS / per_env_param_block), dev_type uint8 [N], valid uint8 [N]."""
+        block = self._dev(block, torch.float64, (_lib.STG_NPARAM, self.n))
+        dev_type = self._dev(dev_type, torch.uint8, (self.n,))
+        valid = self._dev(valid, torch.uint8, (self.n,))
+        torch.cuda.synchronize(self.device)
+        _lib.check(self.lib.stg_set_params_per_env(self._ctx, _ptr(block), _ptr(dev_type), _ptr(valid)))
+        self._cls = None
+        self.n_classes = 0
+
     def thermal_strength(self, cls=0) -> float:
         out = C.c_double()
         _lib.check(self.lib.stg_thermal_strength(self._ctx, cls, C.byref(out)))

@@ -366,3 +366,60 @@ def flatten_params(device: BaseSpintronicDevice) -> "_lib.StgDeviceParams":
     p.dev_type = _lib.DEV_TYPES[device.device_type]
     p.params_valid = int(params_valid_as_stt(d))
     return p
+
+
+# double-valued fields of stg_device_params in declaration order (= the rows of the per-env parameter block)
+PARAM_ROWS = (["damping", "ms", "ku", "volume", "polarization"] + [f"easy_axis{k}" for k in range(3)]
+              + [f"demag{k}" for k in range(3)] + ["a_ex", "area", "r_p", "r_ap"] + [f"ref_m{k}" for k in range(3)]
+              + ["r_series", "sot_tau_dl", "sot_tau_fl"] + [f"sot_sigma{k}" for k in range(3)]
+              + ["vcma_xi", "vcma_td", "vcma_vbd"] + [f"shape_demag{k}" for k in range(3)])
+assert len(PARAM_ROWS) == _lib.STG_NPARAM
+
+# reference dict key -> row name(s) of the per-env block that a per-env override of that key fills
+_OVERRIDE_ROWS = {
+    "damping": ["damping"], "saturation_magnetization": ["ms"], "uniaxial_anisotropy": ["ku"], "volume": ["volume"],
+    "polarization": ["polarization"], "easy_axis": [f"easy_axis{k}" for k in range(3)],
+    "demag_factors": [f"demag{k}" for k in range(3)], "exchange_constant": ["a_ex"], "area": ["area"],
+    "resistance_parallel": ["r_p"], "resistance_antiparallel": ["r_ap"],
+    "reference_magnetization": [f"ref_m{k}" for k in range(3)],
+}
+
+
+def per_env_param_block(base: "_lib.StgDeviceParams", n: int, overrides: Dict[str, Any]):
+    """Per-env parameter block for `stg_set_params_per_env` (device-to-device variation / domain randomisation): every
+    env starts from the flattened `base` record and the reference-style keys in `overrides` replace single fields with
+    arrays of length n (vectors: shape [n, 3]).  Returns (block float64 [STG_NPARAM, n], dev_type uint8 [n], valid uint8
+    [n]); `valid` is the per-env outcome of the reference's ``validate_parameters(..., 'stt_mram')`` gate
+    (utils/validation.py:176-234) evaluated on the overridden values."""
+    flat = {}
+    for name, _ in base._fields_:
+        v = getattr(base, name)
+        if hasattr(v, "__len__"):
+            for k in range(len(v)):
+                flat[f"{name}{k}"] = float(v[k])
+        else:
+            flat[name] = v
+    block = np.empty((_lib.STG_NPARAM, n), dtype=np.float64)
+    for r, name in enumerate(PARAM_ROWS):
+        block[r] = flat[name]
+    for key, val in overrides.items():
+        if key not in _OVERRIDE_ROWS:
+            raise ValueError(f"per-env override of '{key}' is not supported (supported: {sorted(_OVERRIDE_ROWS)})")
+        rows = _OVERRIDE_ROWS[key]
+        arr = np.asarray(val, dtype=np.float64)
+        if arr.shape != ((n,) if len(rows) == 1 else (n, 3)):
+            raise ValueError(f"per-env '{key}' must have shape {(n,) if len(rows) == 1 else (n, 3)}, got {arr.shape}")
+        for k, rname in enumerate(rows):
+            block[PARAM_ROWS.index(rname)] = arr if len(rows) == 1 else arr[:, k]
+    row = {name: block[r] for r, name in enumerate(PARAM_ROWS)}
+    e = np.stack([row["easy_axis0"], row["easy_axis1"], row["easy_axis2"]], axis=1)
+    with np.errstate(invalid="ignore"):
+        valid = (np.isfinite(e).all(axis=1) & (np.linalg.norm(e, axis=1) >= 1e-12)
+                 & np.isfinite(row["volume"]) & (row["volume"] >= 1e-30) & (row["volume"] > 0)
+                 & np.isfinite(row["ms"]) & (row["ms"] >= 1e3)
+                 & np.isfinite(row["damping"]) & (row["damping"] >= 0) & (row["damping"] <= 1)
+                 & np.isfinite(row["ku"]) & (row["ku"] >= 1e3)
+                 & np.isfinite(row["polarization"]) & (row["polarization"] >= 0) & (row["polarization"] <= 1))
+    valid &= bool(base.params_valid)          # (a base dict that fails the gate, e.g. without 'polarization', stays a no-op)
+    dev_type = np.full(n, int(base.dev_type), dtype=np.uint8)
+    return block, dev_type, valid.astype(np.uint8)

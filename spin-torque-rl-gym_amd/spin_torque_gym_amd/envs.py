@@ -95,6 +95,7 @@ class SpinTorqueVecEnv:
                  autoreset: bool = False, skip_done: bool = False, device_index: int = 0, env_id0: int = 0,
                  max_attempts: int = 200_000, lane_sort: Optional[bool] = None, wave_spec: Optional[bool] = None, torque_model: str = "reference",
                  noise_model: str = "white", correlation_time: float = 1e-12,
+                 per_env_params: Optional[Dict[str, Any]] = None,
                  backend=None):
         self.num_envs = int(num_envs)
         factory = DeviceFactory()
@@ -127,7 +128,16 @@ class SpinTorqueVecEnv:
         # oracle for the gloo runs and as the comparator); the product default is the HIP library, nothing else.
         factory_fn = HipBackend if backend is None else backend
         self.backend = factory_fn(self.num_envs, self.cfg, device_index, env_id0)
-        self.backend.set_params([flatten_params(d) for d in self.devices], class_index)
+        if per_env_params:
+            # device-to-device variation: every env gets its own record (one device class as the base); keys are the
+            # reference's device_params keys, values arrays of length num_envs ([num_envs, 3] for vectors)
+            if len(self.devices) != 1:
+                raise ValueError("per_env_params needs exactly one base device class")
+            from .devices import per_env_param_block
+            self.backend.set_params_per_env(*per_env_param_block(flatten_params(self.devices[0]), self.num_envs,
+                                                                  per_env_params))
+        else:
+            self.backend.set_params([flatten_params(d) for d in self.devices], class_index)
         self.single_action_space = _box([-max_current, 0.0], [max_current, max_duration], dtype=np.float32)
         self.single_observation_space = _box(-np.inf, np.inf, shape=(12,), dtype=np.float32)
         self._needs_reset = True

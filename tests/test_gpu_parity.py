@@ -980,3 +980,75 @@ def test_c_abi_error_behaviour(stg):
     assert lib.stg_get_counters(None, out, 0) < 0 and lib.stg_thermal_strength(ctx, 5, C.byref(C.c_double())) < 0
     lib.stg_destroy(ctx)
     lib.stg_destroy(None)                                                          # a no-op, like free(NULL)
+
+
+@pytest.mark.parametrize("solver,thermal", [("rk4", False), ("rk4", True), ("rk45", True), ("euler", False)])
+def test_per_env_parameters(stg, solver, thermal):
+    """stg_set_params_per_env: every env carries its own device record.  (i) against the class-table path
+    with one class per env (<= 64 envs): bit-identical, the lane derives its constants with the host's arithmetic;
+    (ii) against the oracle with one class per env at 200 envs incl. tilted axes and out-of-range values (validator
+    gate -> no-op); (iii) sizes that take the 4-wavefront layout elsewhere (65 536 envs) run and keep |m| = 1."""
+    from helpers import OracleBackend, unit_rows
+    rng = np.random.default_rng(77)
+    vol0 = 9.7e-6 if solver == "rk45" else 8.75e-11
+
+    def variation(n, tilt):
+        ov = dict(volume=vol0 * 10 ** rng.uniform(-0.3, 0.3, n), damping=10 ** rng.uniform(-2.2, -1.0, n),
+                  uniaxial_anisotropy=rng.uniform(6e5, 1.4e6, n), saturation_magnetization=rng.uniform(6e5, 1.0e6, n),
+                  polarization=rng.uniform(0.3, 0.9, n), resistance_parallel=rng.uniform(800, 1500, n))
+        if tilt:
+            ax = np.tile(np.array([0.0, 0.0, 1.0]), (n, 1)); ax[:, :2] = rng.normal(0, 0.2, (n, 2))
+            ov["easy_axis"] = ax
+        return ov
+
+    def dicts(n, ov):
+        out = []
+        for i in range(n):
+            d = stt_default_params()
+            for k, v in ov.items():
+                d[k] = np.array(v[i]) if np.ndim(v[i]) else float(v[i])
+            out.append(d)
+        return out
+
+    for n, tilt, backend_ref in ((64, False, None), (200, True, OracleBackend)):
+        ov = variation(n, tilt)
+        if backend_ref is OracleBackend:
+            ov["uniaxial_anisotropy"][3] = 500.0        # below the validator's 1e3: that env's steps are no-ops
+        m0 = unit_rows(rng, n)
+        tgt = np.where(rng.integers(0, 2, (n, 1)) == 0, 1.0, -1.0) * np.array([[0.0, 0.0, 1.0]])
+        acts = [_uniform_actions(2e6, 1e-10, 2e-10)(rng, n, k) for k in range(2)]
+        kw = dict(include_thermal_fluctuations=thermal, solver=solver, seed=5)
+        e1 = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(volume=vol0), per_env_params=ov, **kw)
+        e2 = stg.SpinTorqueVecEnv(n, device_type=["stt_mram"] * n, device_params=dicts(n, ov),
+                                  class_index=np.arange(n).astype(np.uint8), backend=backend_ref, **kw)
+        outs = []
+        for env in (e1, e2):
+            env.reset(options={"initial_state": m0, "target_state": tgt})
+            rec = []
+            for a in acts:
+                o, r, te, tr, info = env.step(torch.from_numpy(a))
+                rec.append((o.cpu().numpy().copy(), info["reward_f64"].cpu().numpy().copy(), info["status"].cpu().numpy().copy(),
+                            env.get_state()["m"].cpu().numpy().copy()))
+            outs.append(rec)
+            env.close()
+        for (o1, r1, s1, m1), (o2, r2, s2, m2) in zip(*outs):
+            assert np.array_equal(s1, s2), (n, solver)
+            if backend_ref is None:
+                assert np.array_equal(m1, m2) and np.array_equal(o1, o2) and np.array_equal(r1, r2), (n, solver)
+            else:
+                tol = (TOL_RK45 if solver == "rk45" else TOL_RK4) * (50 if thermal else 1)
+                assert np.abs(m1 - m2).max() <= tol, (n, solver, np.abs(m1 - m2).max())
+                assert np.allclose(o1, o2, rtol=3e-7, atol=1e-9) and np.allclose(r1, r2, rtol=1e-9, atol=1e-9)
+        if backend_ref is OracleBackend and solver != "rk45":      # (the gate belongs to RobustLLGSSolver, LLGSSolver has none)
+            assert outs[0][0][2][3] == 1              # STG_STATUS_NOOP for the env the validator gate rejects
+    if solver == "rk4" and not thermal:
+        n = 65536
+        env = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(volume=vol0), per_env_params=variation(n, False),
+                                   include_thermal_fluctuations=True, solver=solver, seed=1, autoreset=True)
+        env.reset(seed=0)
+        a = torch.from_numpy(_uniform_actions(2e6, 1e-10, 3e-10)(rng, n, 0))
+        for _ in range(2):
+            obs, *_ = env.step(a)
+        m = env.get_state()["m"]
+        assert torch.isfinite(obs).all() and torch.all(torch.abs(torch.linalg.norm(m, dim=0) - 1) < 1e-14)
+        env.close()
