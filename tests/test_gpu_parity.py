@@ -1052,3 +1052,32 @@ def test_per_env_parameters(stg, solver, thermal):
         m = env.get_state()["m"]
         assert torch.isfinite(obs).all() and torch.all(torch.abs(torch.linalg.norm(m, dim=0) - 1) < 1e-14)
         env.close()
+
+
+def test_switching_statistics_independent_streams(stg):
+    """BASELINE config 3 gate: with the thermal field on, outcome statistics must match the CPU restatement run with its
+    OWN random stream.  In every regime the validator admits, the reference's Brown field (no 1/sqrt(dt)) is
+    too weak to switch anything by itself (final-state spread ~1e-6, golden G10); the one place where it decides the
+    outcome is the spin-torque-dominated small-volume regime, where it tips a sub-step between "components overflow ->
+    reset to +z -> solve succeeds" and "norm overflows -> zero row -> solve fails, state kept" (H3).  There the fraction
+    of failed solves and the fraction of switched envs are genuinely random: HIP (65 536 envs, seed A) and oracle
+    (4096 envs, seed B) must agree within the binomial error of the smaller sample."""
+    from helpers import OracleBackend
+    par = stt_default_params(volume=1e-28)
+    m0 = np.array([0.05, 0.0, 1.0]); m0 /= np.linalg.norm(m0)
+    stats = []
+    for n, backend, seed in ((65536, None, 11), (4096, OracleBackend, 22)):
+        env = stg.SpinTorqueVecEnv(n, device_params=par, include_thermal_fluctuations=True, solver="rk4", seed=seed, backend=backend)
+        env.reset(options={"initial_state": np.tile(m0, (n, 1)), "target_state": np.tile([0.0, 0.0, -1.0], (n, 1))})
+        a = np.empty((n, 2), dtype=np.float32); a[:, 0] = 5e5; a[:, 1] = 2e-10
+        _, _, te, tr, info = env.step(torch.from_numpy(a))
+        st = info["status"].cpu().numpy()
+        mz = env.get_state()["m"].cpu().numpy()[2]
+        stats.append((float((st == 1).mean()), float((mz < 0).mean()), n))
+        env.close()
+    (f_hip, s_hip, _), (f_cpu, s_cpu, n_cpu) = stats
+    print("failed solves: HIP %.4f CPU %.4f; switched: HIP %.4f CPU %.4f" % (f_hip, f_cpu, s_hip, s_cpu))
+    assert 0.05 < f_cpu < 0.95 and 0.05 < s_cpu < 0.95            # the regime is genuinely stochastic
+    for a_, b_ in ((f_hip, f_cpu), (s_hip, s_cpu)):
+        sigma = np.sqrt(b_ * (1 - b_) / n_cpu)
+        assert abs(a_ - b_) <= 4 * sigma + 1e-3, (a_, b_, sigma)
