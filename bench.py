@@ -125,7 +125,7 @@ def run_config(n_local, solver, thermal, steps, warmup, rank, world, device_inde
         one_step(k)
     torch.cuda.synchronize(dev)
 
-    def timed_block():
+    def timed_block(gather=True):
         """EXACTLY `steps` steps between barrier + synchronize on both sides; also the same span seen from the device."""
         backend.counters(reset=True)
         starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
@@ -139,11 +139,11 @@ def run_config(n_local, solver, thermal, steps, warmup, rank, world, device_inde
             starts[k].record()
             backend.step(acts[warmup + k], autoreset=True)          # the step kernel, on torch's current stream
             ends[k].record()
-            if world > 1:
+            if world > 1 and gather:
                 if k:
                     env.gather_end(unpack=False)                     # step k-1's gather ran under step k's kernel
                 env.gather_begin()                                   # the single collective of a step, on its own stream
-        if world > 1:
+        if world > 1 and gather:
             env.gather_end(unpack=False)
         fin.record()
         torch.cuda.synchronize(dev)
@@ -173,8 +173,10 @@ def run_config(n_local, solver, thermal, steps, warmup, rank, world, device_inde
         if not hiccup or blocks >= 3:
             break
     c = backend.counters()
+    # SURVEY 8e "report both": a learner that is data-parallel over the same ranks needs no gather at all
+    wall_ng = timed_block(gather=False)[0] if world > 1 else None
     env.close()
-    return dict(wall_s=wall, device_span_s=dev_span, blocks_timed=blocks, kernel_ms_avg=float(np.mean(kern_ms)), kernel_ms_min=float(np.min(kern_ms)),
+    return dict(wall_no_gather_s=wall_ng, wall_s=wall, device_span_s=dev_span, blocks_timed=blocks, kernel_ms_avg=float(np.mean(kern_ms)), kernel_ms_min=float(np.min(kern_ms)),
                 env_steps=c["env_steps"], work_units=c["work_units"], noop_steps=c["noop_steps"])
 
 
@@ -392,6 +394,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall_s / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "blocks_timed": meas["blocks_timed"],
+        "no_gather": None,
         "config": {"workload": f"cfg3: {n_local} STT-MRAM envs/GPU, thermal {'on 300K (in-kernel Philox)' if args.thermal else 'off'}, "
                                f"solver={args.solver} ({'LLGSSolver SciPy-RK45 rtol1e-6 atol1e-9 max_step 1ps' if args.solver == 'rk45' else 'SimpleLLGSSolver fixed-step dt<=1ps'}), "
                                f"full env.step, J~U[-2e6,2e6], pulse~U[0.1,1]ns f32, volume={volume_for(args.solver):g}, autoreset",
@@ -400,6 +403,12 @@ def main():
         "roofline": roofline(meas, n_local, args.steps, args.solver, thermal=args.thermal,
                              sorted_schedule=(lane_sort if lane_sort is not None else True)),
     }
+    if world > 1:
+        wng = torch.tensor([meas["wall_no_gather_s"]], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(wng, op=dist.ReduceOp.MAX)
+        out["no_gather"] = {"value": round(n_total * args.steps / float(wng.item()), 1), "unit": "env-steps/s",
+                            "ms_per_step": round(float(wng.item()) / args.steps * 1e3, 4),
+                            "note": "same run without the per-step all-gather (learner data-parallel over the same ranks)"}
     if rank == 0 and world == 1 and args.also:
         also = []
         for name, n, solver, thermal, mixed, tm in (
