@@ -232,12 +232,16 @@ struct NormalStream {
         // (v_alignbit_b32 forms {0x7f, x} >> 9 = 0x3F800000 | (x >> 9) in one instruction)
         return __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, next(), 9u)) - 0.99999994f;
     }
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     __device__ __forceinline__ void pair(float& a, float& b) {
-        const float u0 = uniform();
-        const float u1 = uniform();
-        const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));   // sqrt(-2 ln u0), raw v_sqrt_f32
-        a = r * __builtin_amdgcn_cosf(u1);
-        b = r * __builtin_amdgcn_sinf(u1);
+        // the two mantissa-trick subtractions and the two final products go through packed fp32 (v_pk_add_f32 /
+        // v_pk_mul_f32: one instruction for both lanes of the pair, same IEEE results)
+        f32x2 u{__uint_as_float(__builtin_amdgcn_alignbit(0x7fu, next(), 9u)), __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, next(), 9u))};
+        u = u - f32x2{0.99999994f, 0.99999994f};
+        const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u.x));   // sqrt(-2 ln u0), raw v_sqrt_f32
+        const f32x2 cs = f32x2{__builtin_amdgcn_cosf(u.y), __builtin_amdgcn_sinf(u.y)} * f32x2{r, r};
+        a = cs.x;
+        b = cs.y;
     }
     __device__ __forceinline__ V3 draw3_even() {
         float a, b, c, d;
