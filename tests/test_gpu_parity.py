@@ -1081,3 +1081,26 @@ def test_switching_statistics_independent_streams(stg):
     for a_, b_ in ((f_hip, f_cpu), (s_hip, s_cpu)):
         sigma = np.sqrt(b_ * (1 - b_) / n_cpu)
         assert abs(a_ - b_) <= 4 * sigma + 1e-3, (a_, b_, sigma)
+
+
+@pytest.mark.parametrize("n", [65537, 70001, 131072 + 4096 + 77, 300000])
+def test_schedule_covers_every_env_exactly_once(stg, n):
+    """Launch sizes that take the 4-wavefront workgroups with ragged tiles: the sorted, XCD-aware schedule (and the
+    workgroup composition rules) must step every env exactly once -- same results as the identity schedule, bit for bit,
+    and the on-device counters must add up."""
+    rng = np.random.default_rng(n)
+    acts = torch.from_numpy(_uniform_actions(2e6, 1e-10, 4e-10)(rng, n, 0))
+    outs = []
+    for ls in (False, True):
+        env = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=True,
+                                   solver="rk4", seed=3, lane_sort=ls)
+        env.reset(seed=7)
+        o, r, te, tr, info = env.step(acts)
+        st = env.get_state()
+        c = env.backend.counters()
+        assert c["env_steps"] == n, (n, ls, c)
+        outs.append((o.clone(), info["reward_f64"].clone(), st["m"].clone(), st["step_count"].clone()))
+        env.close()
+    for x, y in zip(*outs):
+        assert torch.equal(x, y), (n,)
+    assert bool((outs[0][3] == 1).all())
