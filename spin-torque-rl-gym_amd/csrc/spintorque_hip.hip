@@ -4,10 +4,12 @@
 //   mx,my,mz, tx,ty,tz, e_tot : f64[N]   step : i32[N]   rng : u32[N]   done : u8[N]       = 65 B/env
 //   class table                : f64[n_classes][C_COUNT]  (derived constants, <= 64 classes)
 //   cls                        : u8[N] (caller-owned) when n_classes > 1
-// One lane per env, 64-thread workgroups (one wavefront each) so that small batches still spread over
-// as many CUs as they have wavefronts; the hot loop lives entirely in registers.  With one device class the
-// constants are read through scalar loads (SGPRs); with several, the table is staged in LDS once per
-// workgroup and each lane reads its class row from there.
+//   per-env parameters         : f64[STG_NPARAM][N] + type/valid u8[N] (library-owned copy), alternative to the class table
+// One lane per env; the step kernel's workgroups hold one integrating wavefront (launches below 65 536 envs: small
+// batches spread over as many CUs as they have wavefronts) or four (one per SIMD of a CU), plus, in the wave-specialised
+// thermal form, one producer wavefront each; the hot loops live entirely in registers.  With one device class the
+// constants are read through scalar loads (SGPRs); with several (or per-env parameters) each lane reads its row of
+// derived constants from LDS.
 #include "../../include/spintorque_hip.h"
 #include "stg_physics.hpp"
 #include <type_traits>
