@@ -264,3 +264,56 @@ class ThermalFluctuations:
             return 0.0
         rate = attempt_frequency * np.exp(-energy_barrier / (self.k_b * self.temperature))
         return min(1 - np.exp(-rate * measurement_time), 1.0)
+
+    # -- Neel-Brown scalars (thermal_model.py:185-336): closed forms, host only ------------------------------------------
+    _YEAR = 365.25 * 24 * 3600
+
+    def _rate(self, energy_barrier, attempt_frequency):
+        return attempt_frequency * np.exp(-energy_barrier / (self.k_b * self.temperature))
+
+    def sample_switching_time(self, energy_barrier, attempt_frequency: float = 1e9) -> float:
+        """thermal_model.py:185-207: exponential waiting time at the Arrhenius rate, from this object's generator."""
+        if self.temperature <= 0:
+            return float("inf")
+        rate = self._rate(energy_barrier, attempt_frequency)
+        return float("inf") if rate <= 0 else self.rng.exponential(1.0 / rate)
+
+    def compute_retention_time(self, energy_barrier, failure_rate: float = 1e-9, attempt_frequency: float = 1e9) -> float:
+        """thermal_model.py:209-232: -ln(failure_rate) / (f0 exp(-E_b / k_B T))."""
+        if self.temperature <= 0 or failure_rate <= 0:
+            return float("inf")
+        return -np.log(failure_rate) / (attempt_frequency * np.exp(-(energy_barrier / (self.k_b * self.temperature))))
+
+    def analyze_thermal_stability(self, device_params: dict, time_scale: float = 10.0) -> dict:
+        """thermal_model.py:234-272 (time_scale in years)."""
+        volume = device_params.get("volume", 1e-24)
+        k_u = device_params.get("uniaxial_anisotropy", 1e6)
+        e_b = k_u * volume
+        delta = self.compute_thermal_barrier(k_u, volume)
+        return {"thermal_stability_factor": delta, "energy_barrier_J": e_b,
+                "energy_barrier_kT": e_b / (self.k_b * self.temperature),
+                "switching_probability": self.compute_switching_probability(e_b, measurement_time=time_scale * self._YEAR),
+                "retention_time_years": self.compute_retention_time(e_b) / self._YEAR,
+                "is_thermally_stable": delta > 40, "temperature_K": self.temperature}
+
+    def generate_temperature_sweep(self, temp_range: Tuple[float, float], device_params: dict, n_points: int = 100) -> dict:
+        """thermal_model.py:274-336: stability factor, one-year switching probability, retention (years) and Brown field
+        strength over a temperature grid; the object's temperature is restored afterwards."""
+        temps = np.linspace(temp_range[0], temp_range[1], n_points)
+        keep = self.temperature
+        volume = device_params.get("volume", 1e-24)
+        k_u = device_params.get("uniaxial_anisotropy", 1e6)
+        damping = device_params.get("damping", 0.01)
+        ms = device_params.get("saturation_magnetization", 800e3)
+        cols = {"thermal_stability_factor": [], "switching_probability": [], "retention_time": [], "noise_strength": []}
+        for t in temps:
+            self.set_temperature(t)
+            e_b = k_u * volume
+            cols["thermal_stability_factor"].append(self.compute_thermal_barrier(k_u, volume))
+            cols["switching_probability"].append(self.compute_switching_probability(e_b, measurement_time=self._YEAR))
+            cols["retention_time"].append(self.compute_retention_time(e_b) / self._YEAR)
+            cols["noise_strength"].append(self.compute_noise_strength(damping, ms, volume))
+        self.set_temperature(keep)
+        out = {"temperature": temps}
+        out.update({k: np.array(v) for k, v in cols.items()})
+        return out

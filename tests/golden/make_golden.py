@@ -517,7 +517,30 @@ def G14():
     save("G14_thermal_ou", **out)
 
 
-ALL = dict(G14=G14, G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11, G12=G12, G13=G13)
+def G15():
+    """thermal_scalars: Neel-Brown closed forms of ThermalFluctuations (thermal_model.py:139-336)."""
+    out = {}
+    params = stt_params()
+    small = dict(params); small["volume"] = 2e-26
+    for tag, T, dp in (("a", 300.0, params), ("b", 350.0, small), ("c", 77.0, small)):
+        tf = ThermalFluctuations(temperature=T, seed=5)
+        st = tf.analyze_thermal_stability(dp, time_scale=10.0)
+        out[f"stab_{tag}"] = np.array([st["thermal_stability_factor"], st["energy_barrier_J"], st["energy_barrier_kT"],
+                                       st["switching_probability"], st["retention_time_years"], float(st["is_thermally_stable"]),
+                                       st["temperature_K"]])
+        e_b = dp["uniaxial_anisotropy"] * dp["volume"]
+        out[f"retention_{tag}"] = np.array([tf.compute_retention_time(e_b), tf.compute_retention_time(e_b, failure_rate=1e-6, attempt_frequency=2e9)])
+        out[f"times_{tag}"] = np.array([tf.sample_switching_time(e_b) for _ in range(8)])
+        sw = tf.generate_temperature_sweep((50.0, 400.0), dp, n_points=9)
+        for k, v in sw.items():
+            out[f"sweep_{tag}_{k}"] = np.asarray(v)
+        out[f"temp_after_{tag}"] = np.array([tf.temperature])
+    out["volumes"] = np.array([params["volume"], small["volume"]])
+    out["ku"] = np.array([params["uniaxial_anisotropy"]])
+    save("G15_thermal_scalars", **out)
+
+
+ALL = dict(G15=G15, G14=G14, G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11, G12=G12, G13=G13)
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

@@ -192,6 +192,25 @@ def test_solver_facades_vs_golden(stg, golden):
         tf = ThermalFluctuations(temperature=300.0, correlation_time=tau, seed=int(seed))
         seq = np.array([tf.generate_thermal_field(0.01, 800e3, 1e-24, dt, correlated=True) for _ in range(64)])
         assert np.array_equal(seq, g14[f"field_{i}"])
+    # Neel-Brown closed forms (G15): stability analysis, retention, seeded switching times, temperature sweep
+    g15 = golden("G15_thermal_scalars")
+    base = stg.DeviceFactory().get_default_parameters("stt_mram")
+    small = dict(base); small["volume"] = float(g15["volumes"][1])
+    for tag, T, dp in (("a", 300.0, base), ("b", 350.0, small), ("c", 77.0, small)):
+        tf = ThermalFluctuations(temperature=T, seed=5)
+        st = tf.analyze_thermal_stability(dp, time_scale=10.0)
+        got = np.array([st["thermal_stability_factor"], st["energy_barrier_J"], st["energy_barrier_kT"], st["switching_probability"],
+                        st["retention_time_years"], float(st["is_thermally_stable"]), st["temperature_K"]])
+        assert np.allclose(got, g15[f"stab_{tag}"], rtol=1e-13, atol=0, equal_nan=True)
+        e_b = dp["uniaxial_anisotropy"] * dp["volume"]
+        assert np.allclose([tf.compute_retention_time(e_b), tf.compute_retention_time(e_b, failure_rate=1e-6, attempt_frequency=2e9)],
+                           g15[f"retention_{tag}"], rtol=1e-13)
+        assert np.allclose([tf.sample_switching_time(e_b) for _ in range(8)], g15[f"times_{tag}"], rtol=1e-13)   # same PCG64 draws
+        sw = tf.generate_temperature_sweep((50.0, 400.0), dp, n_points=9)
+        for k, v in sw.items():
+            assert np.allclose(v, g15[f"sweep_{tag}_{k}"], rtol=1e-13, atol=0), (tag, k)
+        assert tf.temperature == float(g15[f"temp_after_{tag}"][0])
+    assert ThermalFluctuations(0.0).compute_retention_time(1e-19) == float("inf")
 
 
 def test_array_env_facade_vs_golden_g13(stg, golden):
