@@ -174,6 +174,45 @@ class SOTMRAMDevice(BaseSpintronicDevice):
         return (self.tau_dl_factor * current_density * np.cross(sigma, magnetization),
                 self.tau_fl_factor * current_density * sigma)
 
+    # -- analysis helpers of the device class (host closed forms, sot_mram.py:230-281,363-435) ----------------------------
+    def compute_power_consumption(self, current_density: float, pulse_duration: float, magnetization=None) -> float:
+        """sot_mram.py:230-255: Joule energy in the heavy-metal line, I^2 R_hm t with R_hm = sheet/(area 1e-12)."""
+        if abs(current_density) < 1e-12:
+            return 0.0
+        current = current_density * self.area
+        voltage = current * self.sheet_resistance_hm / (self.area * 1e-12)
+        return voltage * current * pulse_duration
+
+    def get_switching_threshold(self) -> Dict[str, float]:
+        """sot_mram.py:257-281: the class's empirical critical current density and the anisotropy field."""
+        alpha = self.device_params["damping"]
+        h_k = 2 * self.device_params["uniaxial_anisotropy"] / (self.mu0 * self.saturation_magnetization)
+        j_c = 5e6 * (1 + alpha) * (1 + h_k / 1e6) / (1 + self.tau_dl_factor)
+        return {"critical_current_density": j_c, "critical_field": h_k,
+                "damping_like_efficiency": self.tau_dl_factor, "field_like_efficiency": self.tau_fl_factor}
+
+    def update_temperature(self, temperature: float) -> None:
+        """sot_mram.py:363-374."""
+        self.device_params["temperature"] = temperature
+        if temperature > 400:
+            warnings.warn(f"High temperature ({temperature} K) may affect device reliability")
+
+    def compute_energy_barrier(self, magnetization) -> float:
+        """sot_mram.py:376-395: K V (1 - cos^2) against the (raw) easy axis."""
+        c = abs(np.dot(magnetization, self.device_params["easy_axis"]))
+        return self.device_params["uniaxial_anisotropy"] * self.volume * (1 - c ** 2)
+
+    def estimate_switching_time(self, current_density: float, temperature: float = 300.0) -> float:
+        """sot_mram.py:397-435: Arrhenius below the critical current (current-assisted barrier), pi alpha / (gamma f_dl J)
+        above it."""
+        if abs(current_density) < 1e-6:
+            return np.inf
+        j_c = self.get_switching_threshold()["critical_current_density"]
+        if abs(current_density) < j_c:
+            e_b = self.device_params["uniaxial_anisotropy"] * self.volume
+            return (1 / 1e9) * np.exp(e_b / (1.38e-23 * temperature) * (1 - abs(current_density) / j_c))
+        return (np.pi * self.device_params["damping"]) / (2.21e5 * self.tau_dl_factor * abs(current_density))
+
 
 class VCMAMRAMDevice(BaseSpintronicDevice):
     """vcma_mram.py:16-257 (parameter surface, effective anisotropy, resistance)."""
@@ -215,6 +254,70 @@ class VCMAMRAMDevice(BaseSpintronicDevice):
         r_ap = self.device_params.get("resistance_antiparallel", 2e3)
         r = r_p + (r_ap - r_p) * (1 - np.dot(magnetization, self._reference_layer())) / 2
         return max(r, 1.0)
+
+    # -- analysis helpers of the device class (host closed forms, vcma_mram.py:60-84,187-234,259-320,400-504) -------------
+    @property
+    def capacitance(self) -> float:
+        """vcma_mram.py:62-70: eps0 eps_r A / t_d unless 'capacitance_per_area' is given."""
+        cpa = self.device_params.get("capacitance_per_area")
+        return (8.854e-12 * self.dielectric_constant * self.area / self.dielectric_thickness) if cpa is None else cpa * self.area
+
+    def compute_switching_probability(self, voltage: float, pulse_duration: float, temperature: float = 300.0,
+                                      initial_state=None) -> float:
+        """vcma_mram.py:187-234: 1 - exp(-f0 exp(-K_eff(V) V / k_B T) t); 1 when the barrier is gone."""
+        e_b = self.effective_anisotropy(voltage) * self.volume
+        kt = 1.38e-23 * temperature
+        if e_b <= 0:
+            return 1.0
+        if kt <= 0:
+            return 0.0
+        return min(1.0 - np.exp(-(1e9 * np.exp(-e_b / kt)) * pulse_duration), 1.0)
+
+    def compute_power_consumption(self, voltage: float, pulse_duration: float, magnetization=None) -> float:
+        """vcma_mram.py:259-287: capacitive charging + ohmic leakage."""
+        if abs(voltage) < 1e-12:
+            return 0.0
+        return 0.5 * self.capacitance * voltage ** 2 + voltage ** 2 * pulse_duration / self.leakage_resistance
+
+    def get_switching_threshold(self) -> Dict[str, float]:
+        """vcma_mram.py:289-320: voltage that cancels the anisotropy (as the class computes it, with the free-layer
+        thickness) and the voltage that leaves a 40 k_B T barrier, both clipped to breakdown."""
+        v_c = min(abs(self.base_anisotropy * self.thickness / self.vcma_coefficient), self.breakdown_voltage)
+        kt = 1.38e-23 * self.device_params.get("temperature", 300.0)
+        need = self.base_anisotropy * self.volume - 40 * kt
+        v_t = (need / (self.vcma_coefficient * self.area)) * self.dielectric_thickness if need > 0 else 0.0
+        return {"critical_voltage": v_c, "thermal_switching_voltage": min(v_t, self.breakdown_voltage),
+                "breakdown_voltage": self.breakdown_voltage, "vcma_coefficient": self.vcma_coefficient}
+
+    def update_temperature(self, temperature: float) -> None:
+        """vcma_mram.py:400-413."""
+        self.device_params["temperature"] = temperature
+        self.thermal_energy = 1.38e-23 * temperature
+        if temperature > 400:
+            warnings.warn(f"High temperature ({temperature} K) may affect VCMA efficiency")
+
+    def compute_energy_barrier(self, magnetization, voltage: float = 0.0) -> float:
+        """vcma_mram.py:415-442: |K_eff(V)| V."""
+        return max(abs(self.effective_anisotropy(voltage)) * self.volume, 0.0)
+
+    def estimate_switching_time(self, voltage: float, temperature: float = 300.0) -> float:
+        """vcma_mram.py:444-478."""
+        if abs(voltage) < 1e-6:
+            return np.inf
+        e_b = self.effective_anisotropy(voltage) * self.volume
+        if e_b <= 0:
+            return 1e-12
+        return (1 / 1e9) * np.exp(e_b / (1.38e-23 * temperature))
+
+    def compute_leakage_current(self, voltage: float) -> float:
+        """vcma_mram.py:480-504: ohmic leakage plus the class's simplified Fowler-Nordheim term above 1e8 V/m."""
+        if abs(voltage) < 1e-12:
+            return 0.0
+        current = voltage / self.leakage_resistance
+        field = abs(voltage) / self.dielectric_thickness
+        if field > 1e8:
+            current += 1e-6 * field * np.exp(-3.5e9 / field) * self.area
+        return current
 
 
 def _shape_demag(aspect_ratio: float):
@@ -291,6 +394,26 @@ class DeviceFactory:
 
     def get_default_parameters(self, device_type: str) -> Dict[str, Any]:
         return _DEFAULTS.get(device_type.lower(), _GENERIC)()
+
+    def validate_parameters(self, device_type: str, device_params: Dict[str, Any]) -> Dict[str, Any]:
+        """device_factory.py:196-227: defaults of the type overlaid with the given values; only the STT-MRAM validator
+        checks anything (:229-246), the other types' validators are empty in the reference."""
+        device_type = device_type.lower()
+        out = dict(self.get_default_parameters(device_type))
+        out.update(device_params)
+        if device_type == "stt_mram":
+            for key in ("volume", "saturation_magnetization", "damping", "uniaxial_anisotropy", "polarization"):
+                if key not in out:
+                    raise ValueError(f"Missing required parameter for STT-MRAM: {key}")
+            if out["volume"] <= 0:
+                raise ValueError("Volume must be positive")
+            if out["saturation_magnetization"] <= 0:
+                raise ValueError("Saturation magnetization must be positive")
+            if not 0 <= out["damping"] <= 1:
+                raise ValueError("Damping must be between 0 and 1")
+            if not 0 <= out["polarization"] <= 1:
+                raise ValueError("Polarization must be between 0 and 1")
+        return out
 
     def create_default_device(self, device_type: str) -> BaseSpintronicDevice:
         return self.create_device(device_type, self.get_default_parameters(device_type))

@@ -163,6 +163,10 @@ class RobustLLGSSolver(SimpleLLGSSolver):
         self.stats["successful_solves" if res["success"] else "failed_solves"] += 1
         return res
 
+    def reset_statistics(self) -> None:
+        """robust_solver.py:330-345 (the retry/fallback counters stay at zero here: the kernels have no retry path)."""
+        self.stats = {"total_solves": 0, "successful_solves": 0, "failed_solves": 0}
+
     def get_statistics(self):
         st = dict(self.stats)
         tot = max(st["total_solves"], 1)

@@ -540,7 +540,41 @@ def G15():
     save("G15_thermal_scalars", **out)
 
 
-ALL = dict(G15=G15, G14=G14, G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11, G12=G12, G13=G13)
+def G16():
+    """device_helpers: analysis helpers of the SOT / VCMA device classes (power, thresholds, barriers, switching times)."""
+    fac = DeviceFactory()
+    out = {}
+    rng = np.random.default_rng(16)
+    ms_ = unit_rows(rng, 6)
+    out["m"] = ms_
+    sot_p = fac.get_default_parameters("sot_mram")
+    sot = fac.create_device("sot_mram", sot_p)
+    th = sot.get_switching_threshold()
+    out["sot_threshold"] = np.array([th["critical_current_density"], th["critical_field"], th["damping_like_efficiency"], th["field_like_efficiency"]])
+    js = np.array([0.0, 1e-7, 1e5, 3e6, 2e7, -5e7, 1e9])
+    out["sot_J"] = js
+    out["sot_power"] = np.array([sot.compute_power_consumption(j, 1e-9, ms_[0]) for j in js])
+    out["sot_time"] = np.array([[sot.estimate_switching_time(j, T) for j in js] for T in (300.0, 400.0)])
+    out["sot_barrier"] = np.array([sot.compute_energy_barrier(m) for m in ms_])
+    vc_p = fac.get_default_parameters("vcma_mram")
+    vc = fac.create_device("vcma_mram", vc_p)
+    th = vc.get_switching_threshold()
+    out["vcma_threshold"] = np.array([th["critical_voltage"], th["thermal_switching_voltage"], th["breakdown_voltage"], th["vcma_coefficient"]])
+    vs = np.array([0.0, 1e-7, 0.05, 0.2, 0.5, -1.0, 1.9, 3.0])
+    out["vcma_V"] = vs
+    out["vcma_power"] = np.array([vc.compute_power_consumption(v, 1e-9) for v in vs])
+    out["vcma_prob"] = np.array([[vc.compute_switching_probability(v, 1e-9, T) for v in vs] for T in (300.0, 0.0)])
+    out["vcma_time"] = np.array([vc.estimate_switching_time(v, 300.0) for v in vs])
+    out["vcma_barrier"] = np.array([vc.compute_energy_barrier(ms_[0], v) for v in vs])
+    out["vcma_leak"] = np.array([vc.compute_leakage_current(v) for v in vs])
+    out["vcma_cap"] = np.array([vc.capacitance])
+    vc.update_temperature(350.0)
+    th = vc.get_switching_threshold()
+    out["vcma_threshold_350"] = np.array([th["critical_voltage"], th["thermal_switching_voltage"]])
+    save("G16_device_helpers", **out)
+
+
+ALL = dict(G16=G16, G15=G15, G14=G14, G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11, G12=G12, G13=G13)
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

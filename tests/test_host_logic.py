@@ -252,3 +252,48 @@ def test_array_env_facade_vs_golden_g13(stg, golden):
     env.reset(seed=0)
     with pytest.raises(ValueError, match="NaN"):
         env.step(np.array([np.nan, 1e6, 1e-9], dtype=np.float32))
+
+
+def test_device_class_analysis_helpers_vs_golden_g16(stg, golden):
+    """Analysis helpers of the SOT / VCMA device classes (host closed forms): power, switching thresholds, energy
+    barriers, switching-time and leakage estimates against the reference classes' outputs (golden G16)."""
+    g = golden("G16_device_helpers")
+    fac = stg.DeviceFactory()
+    ms_ = g["m"]
+    sot = fac.create_device("sot_mram", fac.get_default_parameters("sot_mram"))
+    th = sot.get_switching_threshold()
+    assert np.allclose([th["critical_current_density"], th["critical_field"], th["damping_like_efficiency"], th["field_like_efficiency"]],
+                       g["sot_threshold"], rtol=1e-14)
+    js = g["sot_J"]
+    assert np.allclose([sot.compute_power_consumption(j, 1e-9, ms_[0]) for j in js], g["sot_power"], rtol=1e-14)
+    with np.errstate(over="ignore"):
+        got = np.array([[sot.estimate_switching_time(j, T) for j in js] for T in (300.0, 400.0)])
+    assert np.allclose(got, g["sot_time"], rtol=1e-13, equal_nan=True)
+    assert np.allclose([sot.compute_energy_barrier(m) for m in ms_], g["sot_barrier"], rtol=1e-14)
+    vc = fac.create_device("vcma_mram", fac.get_default_parameters("vcma_mram"))
+    th = vc.get_switching_threshold()
+    assert np.allclose([th["critical_voltage"], th["thermal_switching_voltage"], th["breakdown_voltage"], th["vcma_coefficient"]],
+                       g["vcma_threshold"], rtol=1e-14)
+    vs = g["vcma_V"]
+    assert np.allclose([vc.compute_power_consumption(v, 1e-9) for v in vs], g["vcma_power"], rtol=1e-14)
+    with np.errstate(over="ignore"):
+        prob = np.array([[vc.compute_switching_probability(v, 1e-9, T) for v in vs] for T in (300.0, 0.0)])
+        times = np.array([vc.estimate_switching_time(v, 300.0) for v in vs])
+    assert np.allclose(prob, g["vcma_prob"], rtol=1e-13, atol=0) and np.allclose(times, g["vcma_time"], rtol=1e-13, equal_nan=True)
+    assert np.allclose([vc.compute_energy_barrier(ms_[0], v) for v in vs], g["vcma_barrier"], rtol=1e-14)
+    assert np.allclose([vc.compute_leakage_current(v) for v in vs], g["vcma_leak"], rtol=1e-14)
+    assert np.isclose(vc.capacitance, g["vcma_cap"][0], rtol=1e-15)
+    vc.update_temperature(350.0)
+    th = vc.get_switching_threshold()
+    assert np.allclose([th["critical_voltage"], th["thermal_switching_voltage"]], g["vcma_threshold_350"], rtol=1e-14)
+
+
+def test_factory_validate_parameters(stg):
+    fac = stg.DeviceFactory()
+    out = fac.validate_parameters("STT_MRAM", {"damping": 0.02})
+    assert out["damping"] == 0.02 and out["volume"] == fac.get_default_parameters("stt_mram")["volume"]
+    with pytest.raises(ValueError, match="Damping"):
+        fac.validate_parameters("stt_mram", {"damping": 1.5})
+    with pytest.raises(ValueError, match="Volume"):
+        fac.validate_parameters("stt_mram", {"volume": 0.0})
+    assert fac.validate_parameters("sot_mram", {"damping": 7.0})["damping"] == 7.0       # the reference's SOT validator is empty
