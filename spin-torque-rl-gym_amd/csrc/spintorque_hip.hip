@@ -10,459 +10,13 @@
 // thermal form, one producer wavefront each; the hot loops live entirely in registers.  With one device class the
 // constants are read through scalar loads (SGPRs); with several (or per-env parameters) each lane reads its row of
 // derived constants from LDS.
-#include "../../include/spintorque_hip.h"
-#include "stg_physics.hpp"
-#include <type_traits>
-
-#include <hip/hip_runtime.h>
+#include "stg_kernels.hpp"
 
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
 #include <string>
-
-using namespace stg;
-
-// ------------------------------------------------------------------------------------------------
-// kernel argument blocks
-// ------------------------------------------------------------------------------------------------
-struct StateView {
-    double *mx, *my, *mz, *tx, *ty, *tz, *etot;
-    int32_t* step;
-    uint32_t* rng;
-    uint8_t* done;
-};
-
-struct CfgView {
-    double temperature, max_step, rtol, atol, max_current, max_duration, thr, w_energy;
-    double temp_norm, inv_max_current, inv_max_duration;   // temperature/300, 1/max_current, 1/max_duration (observation)
-    double inv_tau;               // 1/noise_corr_time when the Ornstein-Uhlenbeck field is selected, else 0 (white field)
-    double targets[STG_MAX_TARGETS][3];
-    uint64_t seed;
-    int64_t max_attempts;
-    int32_t max_steps, n_targets, skip_done;
-};
-
-// Per-env parameter block (stg_set_params_per_env): STG_NPARAM rows of N doubles in the field order of
-// stg_device_params, plus the device type and the host-evaluated validity flag per env.
-struct EnvParams {
-    const double* soa;        // [STG_NPARAM][N] or nullptr
-    const uint8_t* type;      // [N]
-    const uint8_t* valid;     // [N]
-    double gamma, temperature;
-};
-
-struct StepArgs {
-    StateView s;
-    CfgView c;
-    int64_t N, env_id0;
-    const double* ctab;
-    const uint8_t* cls;
-    int32_t ncls;
-    EnvParams ep;                 // per-env parameters (soa == nullptr: class table)
-    int32_t force_wg1;
-    const void* actions;          // [K][2][N]
-    int32_t K, out_every, autoreset;
-    const uint32_t* perm;         // lane -> env (duration-sorted schedule) or nullptr
-    unsigned long long* counters; // [4]: env-steps, integrator sub-steps/attempts, RHS evaluations, no-op steps
-    float* obs;                   // [K or 1][12][N]
-    float* final_obs;             // [K or 1][12][N] or nullptr: terminal observation of envs auto-reset at that step
-    float* reward;                // [K or 1][N]
-    double *reward64, *energy;
-    uint8_t *term, *trunc, *status;
-};
-
-struct SolveArgs {
-    CfgView c;
-    int64_t N, env_id0;
-    const double* ctab;
-    const uint8_t* cls;
-    int32_t ncls;
-    const double *m0, *J, *T;
-    uint32_t env_step;
-    double* m_final;
-    int32_t* n_points;
-    uint8_t* success;
-    int32_t traj_cap;
-    double *traj_t, *traj_m, *traj_e;
-};
-
-// ------------------------------------------------------------------------------------------------
-// device helpers
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void load_env_params(const EnvParams& e, int64_t N, int64_t i, stg_device_params& p) {
-    const double* q = e.soa + i;
-    int r = 0;
-    auto nx = [&]() { const double v = q[(int64_t)r * N]; ++r; return v; };
-    p.damping = nx(); p.ms = nx(); p.ku = nx(); p.volume = nx(); p.polarization = nx();
-    for (int k = 0; k < 3; ++k) p.easy_axis[k] = nx();
-    for (int k = 0; k < 3; ++k) p.demag[k] = nx();
-    p.a_ex = nx(); p.area = nx(); p.r_p = nx(); p.r_ap = nx();
-    for (int k = 0; k < 3; ++k) p.ref_m[k] = nx();
-    p.r_series = nx(); p.sot_tau_dl = nx(); p.sot_tau_fl = nx();
-    for (int k = 0; k < 3; ++k) p.sot_sigma[k] = nx();
-    p.vcma_xi = nx(); p.vcma_td = nx(); p.vcma_vbd = nx();
-    for (int k = 0; k < 3; ++k) p.shape_demag[k] = nx();
-    p.dev_type = (int32_t)e.type[i];
-    p.params_valid = (int32_t)e.valid[i];
-}
-
-// Returns this lane's row of derived constants.  One class: the (wave-uniform) global table row, which the compiler
-// turns into scalar loads.  MULTI: the class table staged in LDS, or -- per-env parameters -- a row per lane derived
-// here from the env's own record (the LDS block holds exactly 64 rows: per-env launches use 64 integrating lanes per
-// workgroup; lanes of a producer wavefront read the row of the integrating lane they mirror).
-template <bool MULTI>
-__device__ __forceinline__ const double* class_row(const double* ctab, const uint8_t* cls, int32_t ncls, int64_t i,
-                                                   bool in_range, double* lds, const EnvParams& ep, int64_t N) {
-    if (MULTI) {
-        if (ep.soa) {
-            const int lane = (int)(threadIdx.x & 63u);
-            if (threadIdx.x < 64 && in_range) {
-                stg_device_params p;
-                load_env_params(ep, N, i, p);
-                derive_row(p, ep.gamma, ep.temperature, lds + lane * C_COUNT);
-            }
-            __syncthreads();
-            return lds + lane * C_COUNT;
-        }
-        for (int j = threadIdx.x; j < ncls * C_COUNT; j += blockDim.x) lds[j] = ctab[j];
-        __syncthreads();
-        const int c = in_range ? (int)cls[i] : 0;
-        return lds + (c < ncls ? c : 0) * C_COUNT;
-    }
-    return ctab;
-}
-
-__device__ __forceinline__ SimpleK load_simple(const double* r) {
-    return SimpleK{V3{r[C_EX], r[C_EY], r[C_EZ]}, r[C_HK], r[C_MS], r[C_ALPHA], r[C_GEFF], r[C_HS_SIMPLE]};
-}
-__device__ __forceinline__ LlgsK load_llgs(const double* r) {
-    return make_llgs(V3{r[C_RX], r[C_RY], r[C_RZ]}, V3{r[C_DX], r[C_DY], r[C_DZ]}, r[C_HK], r[C_HEX], r[C_ALPHA], r[C_GAMMA],
-                     r[C_HS_LLGS]);
-}
-__device__ __forceinline__ LlgsEnergyK load_energy(const double* r) {
-    return LlgsEnergyK{r[C_KUV], r[C_EDEMAG], V3{r[C_RX], r[C_RY], r[C_RZ]}, V3{r[C_NX], r[C_NY], r[C_NZ]}};
-}
-
-template <int SOLVER, bool THERMAL, bool RECORD, bool AXIS_Z, bool DEVPHYS, class NSRC>
-__device__ __forceinline__ SolveOut run_solver(const V3& m, double J, double T, const double* row, const CfgView& c,
-                                               const RngKey& rk, const Recorder& rec, NSRC& ns, bool enabled) {
-    if (SOLVER == STG_SOLVER_RK45) {
-        const LlgsK k = load_llgs(row);
-        LlgsEnergyK ek{};
-        if (RECORD) ek = load_energy(row);
-        return llgs_solve<THERMAL, RECORD, AXIS_Z>(m, J, T, k, row[C_BETA], row[C_BETAP], c.rtol, c.atol, c.max_step,
-                                                   c.max_attempts, rk, rec, ek, ns, enabled);
-    }
-    const SimpleK k = load_simple(row);
-    DevTorque dv{0.0, 0.0, V3{0.0, 1.0, 0.0}, k.hk, false};
-    double pol = row[C_POL];
-    if (DEVPHYS) {
-        // per-lane coefficients of the device-physics torque model (stg_physics.hpp: DevTorque)
-        const int kind = (int)row[C_DEVTYPE];
-        const bool sot = kind == STG_DEV_SOT;
-        dv.any_sot = __ballot(sot) != 0ull;
-        dv.sigma = V3{row[C_SIGX], row[C_SIGY], row[C_SIGZ]};
-        if (sot) {
-            pol = 0.0;                                           // no Slonczewski term for SOT lanes
-            dv.sdl = row[C_SOT_DL] * J / row[C_MSV];
-            dv.sfl = row[C_SOT_FL] * J / row[C_MSV];
-        }
-        if (kind == STG_DEV_VCMA) {
-            // V = J R(m_before) A, the voltage the env computes for this pulse (spin_torque_env.py:475-477)
-            const V3 ref{row[C_REFX], row[C_REFY], row[C_REFZ]};
-            const double r = resistance(m, kind, row[C_RP], row[C_RAP], row[C_TMR], ref, row[C_RSERIES]);
-            const double keff = vcma_keff(J * r * row[C_AREA], row[C_KU], row[C_VCMA_XI], row[C_VCMA_TD2], row[C_VCMA_VBD]);
-            dv.hk_pulse = (2 * keff) / row[C_MU0MS];
-        }
-    }
-    return simple_solve<SOLVER == STG_SOLVER_EULER ? 1 : 0, THERMAL, RECORD, AXIS_Z, DEVPHYS>(
-        m, J, T, k, pol, row[C_MSV], row[C_VALID] != 0.0, c.temperature, c.max_step, rk, rec, dv, ns, c.inv_tau, enabled);
-}
-
-// SpinTorqueEnv.reset draws (spin_torque_env.py:286-299) from the device generator: normal(0,1,3) normalised and a
-// uniform choice among the target states, from this env's stream tagged 0xFFFFFFFF (the thermal field uses tag 0).
-__device__ __forceinline__ void device_reset_draw(uint64_t seed, uint64_t env_id, uint32_t rng_step, const CfgView& c,
-                                                  bool draw_m, bool draw_t, V3& m, V3& tgt) {
-#pragma clang fp contract(off)
-    NormalStream ns;
-    ns.init(seed ^ 0x9E3779B97F4A7C15ull, env_id, rng_step, 0xFFFFFFFFu);
-    const V3 z = ns.draw3_even();
-    const uint32_t r = ns.next();
-    if (draw_m) {
-        const double s2 = dot(z, z), inv = rsqrt_fast(s2);
-        m = (s2 < 1e-24) ? V3{0.0, 0.0, 1.0} : V3{z.x * inv, z.y * inv, z.z * inv};
-    }
-    if (draw_t) {
-        const int idx = (int)__umulhi(r, (uint32_t)c.n_targets);
-        tgt = V3{c.targets[idx][0], c.targets[idx][1], c.targets[idx][2]};
-    }
-}
-
-// A12: _get_observation (vector mode), written component-major.
-__device__ __forceinline__ void write_obs(float* obs, int64_t N, int64_t i, const V3& m, const V3& tgt, const double* row,
-                                          const CfgView& c, int32_t step, double etot, double J, double T) {
-#pragma clang fp contract(off)
-    const V3 ref{row[C_REFX], row[C_REFY], row[C_REFZ]};
-    const double r = resistance(m, (int)row[C_DEVTYPE], row[C_RP], row[C_RAP], row[C_TMR], ref, row[C_RSERIES]);
-    obs[0 * N + i] = obs_cast(m.x);
-    obs[1 * N + i] = obs_cast(m.y);
-    obs[2 * N + i] = obs_cast(m.z);
-    obs[3 * N + i] = obs_cast(tgt.x);
-    obs[4 * N + i] = obs_cast(tgt.y);
-    obs[5 * N + i] = obs_cast(tgt.z);
-    obs[6 * N + i] = obs_cast(r / row[C_RP]);
-    // (the normalisations by run constants are multiplications by host-computed reciprocals: <= 1 ulp of fp64 away
-    // from the reference's quotients, before the cast to fp32)
-    obs[7 * N + i] = obs_cast(c.temp_norm);
-    obs[8 * N + i] = obs_cast((double)(c.max_steps - step) / (double)c.max_steps);
-    obs[9 * N + i] = obs_cast(etot * 1e12);
-    obs[10 * N + i] = obs_cast(J * c.inv_max_current);
-    obs[11 * N + i] = obs_cast(T * c.inv_max_duration);
-}
-
-constexpr int COUNTER_STRIPES = 1024;     // copies of the on-device counters (one 64-byte line each)
-constexpr int COUNTER_STRIDE = 8;         // u64 per stripe
-
-// Adds the sums of three per-lane counters over the executing lanes of the wavefront to dst[0], dst[1], dst[3] with one
-// global atomic each.  The lanes accumulate in LDS (ds_add_u64 on one address: the LDS unit serialises the lanes while
-// the wavefront issues nothing); LDS operations of one wavefront complete in order, so no barrier is needed.
-__device__ __forceinline__ void wave_add3(unsigned long long* dst, unsigned long long* lds3, unsigned long long v0,
-                                          unsigned long long v1, unsigned long long v3) {
-    const bool first = (int)__lane_id() == __builtin_ctzll(__ballot(1));
-    if (first) { lds3[0] = 0; lds3[1] = 0; lds3[2] = 0; }
-    atomicAdd(&lds3[0], v0);
-    atomicAdd(&lds3[1], v1);
-    if (__ballot(v3 != 0) != 0ull) atomicAdd(&lds3[2], v3);
-    if (first) {
-        const unsigned long long s0 = lds3[0], s1 = lds3[1], s3 = lds3[2];
-        if (s0) atomicAdd(dst + 0, s0);
-        if (s1) atomicAdd(dst + 1, s1);
-        if (s3) atomicAdd(dst + 3, s3);
-    }
-}
-
-constexpr int PLAN_DUR = 256;         // 20 ps of pulse duration per bucket at the default 5 ns maximum
-constexpr int PLAN_BUCKETS = 3 * PLAN_DUR;   // x device kind (device-physics torque model: type-uniform wavefronts)
-constexpr int PLAN_THREADS = 1024;
-constexpr int PLAN_ITEMS = 4;
-constexpr int TILE_ENVS = PLAN_THREADS * PLAN_ITEMS;   // 4096 envs sorted together (one plan workgroup)
-constexpr int TILE_WAVES = TILE_ENVS / 64;             // = 64 wavefronts of the step launch
-
-// Which 64-slot block of the schedule integrating wavefront `cw` of workgroup `b` takes; a workgroup holds WGW = 1 or 4
-// integrating wavefronts.
-//  * WGW = 4 (launches of at least one such workgroup per CU): the dispatcher puts the wavefronts of a 256-thread
-//    workgroup on the four SIMDs of a CU one each, deterministically -- 64-thread workgroups were observed to double up
-//    on some SIMDs and leave others empty (tools/probes/wave_placement.hip: up to 104 of 1024 SIMDs with two wavefronts
-//    at 65 536 envs), which a launch with one wavefront per SIMD pays for in full.
-//  * With the sorted schedule, a tile's workgroups share an XCD (so its L2 merges their scattered accesses): workgroups
-//    are observed to be dealt round-robin over the 8 XCDs (b % 8 labels the XCD group; a speed heuristic only, never a
-//    correctness assumption), XCD group r takes tiles r, r+8, r+16, ... and walks them rank-major (longest wavefronts of
-//    every tile first).  Tiles beyond the last complete group of 8 keep the identity map.
-//  * Which wavefronts of a tile share a workgroup (= a CU): with one workgroup per CU, strided ranks u, u+16, u+32, u+48
-//    -- measured 1.96 ms against 2.23 ms for consecutive ranks on the RK45 step at 65 536 envs: four wavefronts that
-//    are busy for the whole launch slow each other down, a long one next to progressively shorter ones does not.
-template <int WGW>
-__device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool sorted, int cw, bool pairs) {
-    constexpr uint32_t TILE_WGS = TILE_WAVES / WGW;                   // workgroups per tile
-    if (!sorted) return (int64_t)b * WGW + cw;
-    if (WGW == 1 && pairs && nwg == 1024) {
-        // Wave-specialised launch with exactly one integrating wavefront per SIMD (65 536 envs; 16 tiles, two per XCD
-        // group).  Observed placement (tools/probes/wave_placement.hip, 1024 x 128 threads): a CU takes the workgroups
-        // q, q+32, q+64, q+96 of its XCD group and the producer of arrival g shares a SIMD with the integrating
-        // wavefront of arrival g+1 (cyclically).  Arrivals alternate between the long half of a tile (ranks j) and the
-        // short half (ranks 63-j): every long integrating wavefront then shares its SIMD with the producer of a short
-        // one, which retires early, and its own producer runs next to a short integrating wavefront.
-        const uint32_t r = b % 8, q = b / 8, g = q / 32, j = q % 32;
-        return (int64_t)((g >> 1) * 8 + r) * TILE_WAVES + ((g & 1) ? (TILE_WAVES - 1 - j) : j);
-    }
-    const uint32_t tiles8 = (nwg / (8 * TILE_WGS)) * 8;              // tiles in complete groups of 8
-    if (b >= tiles8 * TILE_WGS) return (int64_t)b * WGW + cw;
-    const uint32_t r = b % 8, q = b / 8;                              // XCD group, position inside the group
-    const uint32_t tiles_per_xcd = tiles8 / 8;
-    const uint32_t u = q / tiles_per_xcd, t = (q % tiles_per_xcd) * 8 + r;
-    // one workgroup per CU at most (everything resident from the start): spread; otherwise keep wavefronts of similar
-    // duration together, so that a workgroup's four SIMD slots come free together for the next one (measured 6.0 ms
-    // against 7.6 ms at 262 144 envs)
-    const uint32_t rank = (nwg <= 256) ? (u + TILE_WGS * cw) : (WGW * u + cw);
-    return (int64_t)t * TILE_WAVES + rank;
-}
-
-// ------------------------------------------------------------------------------------------------
-// env.step kernel (A10-A14 around the solver), K fused steps per launch
-// ------------------------------------------------------------------------------------------------
-// Workgroup = WGW integrating wavefronts: 4 (256 envs, one wavefront per SIMD of the CU) for launches that fill the chip,
-// 1 for smaller ones (which then spread over four times as many CUs).
-// PC = producer/consumer wave specialisation (thermal only, launches of at most 65 536 envs): every integrating
-// wavefront gets a second wavefront that runs the normal streams of the same envs one chunk ahead into LDS
-// (stg_physics.hpp: SharedNormalsT).  Same values in the same order, so results are identical.  It is launched with
-// WGW = 1 (128-thread workgroups): the dispatcher was observed to put the two wavefronts on different SIMDs and to give
-// every SIMD one integrating and one producing wavefront at 65 536 envs (tools/probes/wave_placement.hip).  The code
-// supports WGW = 4 (producer 4+w serves integrating wavefront 3-w, all eight in lockstep) but that form measured no
-// better for RK45 and 8 % worse for RK4, so it is not instantiated.
-template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, bool DEVPHYS, typename AT, bool PC, int WGW>
-#ifndef STG_STEP_ATTR
-#define STG_STEP_ATTR
-#endif
-__global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR stg_step_kernel(const StepArgs a) {
-    // the env-step arithmetic around the solver (energy, reward, flags) has no contraction: same roundings in every
-    // instantiation, and the same as NumPy's
-#pragma clang fp contract(off)
-    static_assert(!PC || THERMAL, "wave specialisation only exists for the thermal kernels");
-    __shared__ double s_tab[MULTI ? STG_MAX_CLASSES * C_COUNT : 1];
-    // normals rings of the wave-specialised kernels (one per integrating wavefront): RK45 hands over finished fields
-    // (double), the fixed-step solvers raw normals (float)
-    constexpr bool FIELD = SOLVER == STG_SOLVER_RK45;
-    using NT = typename std::conditional<FIELD, double, float>::type;
-    constexpr int RING = 2 * SHARED_CHUNK_MAX * 64;
-    __shared__ NT s_norm[PC ? WGW * RING : 1];
-    __shared__ int s_alive[2 * WGW], s_go[2 * WGW];
-    __shared__ unsigned long long s_cnt[WGW * 3];
-    __shared__ uint32_t s_rng[PC ? WGW * 64 : 1];
-    const int lane = (int)(threadIdx.x & 63u);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const bool producer = PC && wave >= WGW;
-    const int cw = producer ? (2 * WGW - 1 - wave) : wave;          // the integrating wavefront this one is, or serves
-    const int64_t lane_slot = stg_slot_block<WGW>(blockIdx.x, gridDim.x, a.perm != nullptr, cw, PC) * 64 + lane;
-    const bool live = lane_slot < a.N;
-    // duration-sorted schedule: slot j of the launch integrates env perm[j], so the 64 lanes of a wavefront have
-    // (nearly) equal trip counts; all state and outputs stay at the env's own index
-    const int64_t i = live ? (a.perm ? (int64_t)a.perm[lane_slot] : lane_slot) : 0;
-    const double* row = class_row<MULTI>(a.ctab, a.cls, a.ncls, i, live, s_tab, a.ep, a.N);
-    // Lanes without an env: the one-wavefront form has no rendezvous after this point and lets them go; in the
-    // wave-specialised form they stay (inert) because every wavefront of the workgroup takes part in every s_barrier.
-    if (!PC && !live) return;
-    const int64_t N = a.N;
-    const uint64_t env_id = (uint64_t)(a.env_id0 + i);
-
-    if (producer) {
-        // per env-step: wait for the stream positions (H1), then stay one chunk ahead of integrating wavefront `cw`.
-        // Normals per chunk: RK45 6 (initial step) then 18 per attempt; RK4 12 per sub-step; Euler and the
-        // Ornstein-Uhlenbeck field 3 per sub-step
-        constexpr int n_first = SOLVER == STG_SOLVER_RK45 ? 6 : (SOLVER == STG_SOLVER_RK4 ? 12 : 3);
-        constexpr int n_chunk = SOLVER == STG_SOLVER_RK45 ? 18 : n_first;
-        const bool ou = a.c.inv_tau > 0.0;
-        const double ghs = FIELD ? load_llgs(row).ghs : 0.0;
-        for (int k = 0; k < a.K; ++k) {
-            __syncthreads();                                       // H1: s_rng / s_go[k & 1] published
-            const int p = (k & 1) * WGW;
-            if (!any_flag<WGW>(s_go + p)) continue;
-            const bool serve = s_go[p + cw] != 0;
-            const RngKey rk{a.c.seed, env_id, s_rng[cw * 64 + lane]};
-            if (SOLVER == STG_SOLVER_RK4 && ou) produce_normals<NT, FIELD, WGW>(s_norm + cw * RING, s_alive, cw, lane, rk, 3, 3, ghs, serve);
-            else produce_normals<NT, FIELD, WGW>(s_norm + cw * RING, s_alive, cw, lane, rk, n_first, n_chunk, ghs, serve);
-        }
-        return;
-    }
-
-    V3 m{a.s.mx[i], a.s.my[i], a.s.mz[i]};          // (lanes without an env read env 0 and never write)
-    V3 tgt{a.s.tx[i], a.s.ty[i], a.s.tz[i]};
-    double etot = a.s.etot[i];
-    int32_t step = a.s.step[i];
-    uint32_t rng = a.s.rng[i];
-    bool done = a.s.done[i] != 0;
-    const AT* act = (const AT*)a.actions;
-    const Recorder norec{};
-    unsigned long long c_steps = 0, c_sub = 0, c_noop = 0;
-
-    for (int k = 0; k < a.K; ++k) {
-        double J, T;
-        parse_action<AT>(act[((int64_t)k * 2 + 0) * N + i], act[((int64_t)k * 2 + 1) * N + i], a.c.max_current,
-                         a.c.max_duration, J, T);
-        const bool last = (k == a.K - 1);
-        const int64_t ko = a.out_every ? k : 0;
-        const bool wr = (a.out_every || last) && live;
-        uint8_t st;
-        double reward, energy = 0.0;
-        bool is_success, truncated;
-        // with skip_done, finished envs are not integrated: a wavefront whose lanes are all done skips the integrator
-        const bool lane_solves = live && !(a.c.skip_done && done);
-        const RngKey rk{a.c.seed, env_id, rng};
-        SolveOut so{m, 0, 0, 0, false};
-        if (PC) {
-            // H1: this wavefront's stream positions and whether it integrates at all; then, if anybody in the workgroup
-            // does, H2 (chunk 0 is in LDS) and the solve, which every integrating wavefront of the workgroup walks chunk
-            // for chunk (lanes that do not integrate are inert)
-            SharedNormalsT<NT, FIELD, WGW> shared{s_norm + cw * RING, s_alive, cw, lane, 0, 0};
-            const int p = (k & 1) * WGW;
-            s_rng[cw * 64 + lane] = rng;
-            const bool mine = __ballot(lane_solves) != 0ull;
-            s_go[p + cw] = mine ? 1 : 0;
-            __syncthreads();                                       // H1
-            if ((WGW == 1) ? mine : any_flag<WGW>(s_go + p)) {
-                __syncthreads();                                   // H2
-                so = run_solver<SOLVER, THERMAL, false, AXIS_Z, DEVPHYS>(m, J, T, row, a.c, rk, norec, shared, lane_solves);
-            }
-        }
-        if (!lane_solves) {
-            st = STG_STATUS_INACTIVE; reward = 0.0;
-            is_success = dot(m, tgt) >= a.c.thr;
-            truncated = step >= a.c.max_steps;
-        } else {
-            const double prev_align = dot(m, tgt);                                   // spin_torque_env.py:338-339
-            if (!PC) {
-                InlineNormals inl;
-                so = run_solver<SOLVER, THERMAL, false, AXIS_Z, DEVPHYS>(m, J, T, row, a.c, rk, norec, inl, true);
-            }
-            if (fabs(J) > 1e-12) {                                                   // spin_torque_env.py:474-480
-                const V3 ref{row[C_REFX], row[C_REFY], row[C_REFZ]};
-                const double r = resistance(m, (int)row[C_DEVTYPE], row[C_RP], row[C_RAP], row[C_TMR], ref, row[C_RSERIES]);
-                const double v = J * r * row[C_AREA];
-                energy = (v * v) / r * T;
-            }
-            if (so.ok) {                                                             // spin_torque_env.py:461-467
-                const double inv = rsqrt_fast(dot(so.m, so.m));
-                m = V3{so.m.x * inv, so.m.y * inv, so.m.z * inv};
-            }
-            etot += energy;
-            step += 1;
-            rng += 1;
-            const double align = dot(m, tgt);                                        // spin_torque_env.py:350-353
-            is_success = align >= a.c.thr;
-            // default reward (spin_torque_env.py:184-207; rewards/composite_reward.py:65-126), H7 sign kept
-            reward = 10.0 * (is_success ? 10.0 : 0.0);
-            reward += (-a.c.w_energy) * (-energy / 1e-12);
-            reward += (align - prev_align);
-            if (isnan(reward) || isinf(reward)) reward = -1.0;                       // monitoring.py:332-348
-            reward = fmin(fmax(reward, -1e6), 1e6);
-            truncated = step >= a.c.max_steps;                                       // spin_torque_env.py:371-372
-            st = so.ok ? (so.resets > 0 ? STG_STATUS_RESET : STG_STATUS_OK) : STG_STATUS_NOOP;
-            c_steps += 1; c_sub += (unsigned long long)so.work; c_noop += so.ok ? 0 : 1;
-            done = is_success || truncated;
-        }
-        // same-step auto-reset: the finished episode's reward/flags go out with this step, the state is redrawn on the
-        // device and the observation handed to the agent is the NEW episode's first one (the terminal observation goes
-        // to final_obs when the caller asked for it)
-        const bool do_reset = a.autoreset && done && live;
-        if (wr && do_reset && a.final_obs) write_obs(a.final_obs + ko * 12 * N, N, i, m, tgt, row, a.c, step, etot, J, T);
-        if (do_reset) {
-            device_reset_draw(a.c.seed, env_id, rng, a.c, true, true, m, tgt);
-            etot = 0.0; step = 0; done = false;
-            J = 0.0; T = 0.0;                       // last_action = zeros after reset (spin_torque_env.py:283)
-        }
-        if (wr) {
-            write_obs(a.obs + ko * 12 * N, N, i, m, tgt, row, a.c, step, etot, J, T);
-            a.reward[ko * N + i] = (float)reward;
-            if (a.reward64) a.reward64[ko * N + i] = reward;
-            if (a.energy) a.energy[ko * N + i] = energy;
-            a.term[ko * N + i] = is_success ? 1 : 0;
-            a.trunc[ko * N + i] = truncated ? 1 : 0;
-            if (a.status) a.status[ko * N + i] = st;
-        }
-    }
-    if (live) {
-        a.s.mx[i] = m.x; a.s.my[i] = m.y; a.s.mz[i] = m.z;
-        a.s.tx[i] = tgt.x; a.s.ty[i] = tgt.y; a.s.tz[i] = tgt.z;
-        a.s.etot[i] = etot;
-        a.s.step[i] = step;
-        a.s.rng[i] = rng;
-        a.s.done[i] = done ? 1 : 0;
-    }
-    // on-device metrics (the reference's EnvironmentMonitor/solver stats are host-side bookkeeping): one atomic per
-    // counter per wavefront, into one of COUNTER_STRIPES copies
-    wave_add3(a.counters + (size_t)((blockIdx.x * WGW + cw) % COUNTER_STRIPES) * COUNTER_STRIDE, s_cnt + cw * 3, c_steps, c_sub, c_noop);
-}
 
 // ------------------------------------------------------------------------------------------------
 // solver-level seam
@@ -876,54 +430,6 @@ int stg_reset(stg_ctx* ctx, const uint8_t* mask, const double* init_m, const dou
     return STG_OK;
 }
 
-extern "C++" {
-constexpr int64_t STG_WG4_MIN_ENVS = 65536;       // 256 CUs x 4 SIMDs x 64 lanes
-
-template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, bool DEVPHYS, int WGW>
-static void launch_step_w(const StepArgs& a, int act_f64, bool pc, hipStream_t st) {
-    const dim3 grid((unsigned)((a.N + WGW * 64 - 1) / (WGW * 64)));
-    if (act_f64)
-        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, double, false, WGW>), grid, dim3(WGW * 64), 0, st, a);
-    else
-        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, float, false, WGW>), grid, dim3(WGW * 64), 0, st, a);
-}
-
-template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, bool DEVPHYS>
-static void launch_step(const StepArgs& a, int act_f64, bool pc, hipStream_t st) {
-    if (THERMAL && !DEVPHYS && pc) {
-        // wave-specialised variant: one integrating + one producing wavefront per workgroup; not built for the
-        // device-physics model
-        constexpr bool PC = THERMAL && !DEVPHYS;
-        const dim3 grid((unsigned)((a.N + 63) / 64));
-        if (act_f64)
-            hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, double, PC, 1>), grid, dim3(128), 0, st, a);
-        else
-            hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, float, PC, 1>), grid, dim3(128), 0, st, a);
-        return;
-    }
-    // workgroups of 4 integrating wavefronts once there is one per CU, of 1 below that
-    if (a.N >= STG_WG4_MIN_ENVS && !a.force_wg1) launch_step_w<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, 4>(a, act_f64, pc, st);
-    else launch_step_w<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, 1>(a, act_f64, pc, st);
-}
-template <int SOLVER, bool AXIS_Z, bool DEVPHYS>
-static void dispatch_step2(const StepArgs& a, bool thermal, bool multi, int act_f64, bool pc, hipStream_t st) {
-    if (thermal) { if (multi) launch_step<SOLVER, true, true, AXIS_Z, DEVPHYS>(a, act_f64, pc, st); else launch_step<SOLVER, true, false, AXIS_Z, DEVPHYS>(a, act_f64, pc, st); }
-    else { if (multi) launch_step<SOLVER, false, true, AXIS_Z, DEVPHYS>(a, act_f64, false, st); else launch_step<SOLVER, false, false, AXIS_Z, DEVPHYS>(a, act_f64, false, st); }
-}
-// axis_z selects the easy-axis = z specialisation of the RHS (Simple: e = +z; LLGS: raw axis and demag along z);
-// devphys the opt-in device-physics torque model (fixed-step solvers only)
-template <int SOLVER>
-static void dispatch_step(const StepArgs& a, bool thermal, bool multi, bool axis_z, bool devphys, int act_f64, bool pc, hipStream_t st) {
-    if (SOLVER != STG_SOLVER_RK45 && devphys) {
-        if (axis_z) dispatch_step2<SOLVER, true, true>(a, thermal, multi, act_f64, pc, st);
-        else dispatch_step2<SOLVER, false, true>(a, thermal, multi, act_f64, pc, st);
-    } else {
-        if (axis_z) dispatch_step2<SOLVER, true, false>(a, thermal, multi, act_f64, pc, st);
-        else dispatch_step2<SOLVER, false, false>(a, thermal, multi, act_f64, pc, st);
-    }
-}
-}  // extern "C++"
-
 int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64, int32_t out_every, int32_t autoreset,
                   float* obs, float* final_obs, float* reward, double* reward_f64, double* energy, uint8_t* terminated,
                   uint8_t* truncated, uint8_t* status, void* stream) {
@@ -966,9 +472,9 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
     // 1 = always, -1 = never.  Results do not depend on it.
     const bool pc = ctx->cfg.wave_spec > 0 || (ctx->cfg.wave_spec == 0 && ctx->N <= STG_WAVE_SPEC_MAX_ENVS);
     switch (ctx->cfg.solver) {
-        case STG_SOLVER_RK4: dispatch_step<STG_SOLVER_RK4>(a, thermal, multi, ctx->axis_z, devphys, act_f64, pc, st); break;
-        case STG_SOLVER_EULER: dispatch_step<STG_SOLVER_EULER>(a, thermal, multi, ctx->axis_z, devphys, act_f64, pc, st); break;
-        default: dispatch_step<STG_SOLVER_RK45>(a, ctx->cfg.thermal != 0, multi, ctx->axis_z_llgs, false, act_f64, pc, st); break;
+        case STG_SOLVER_RK4: stg_dispatch_step_rk4(a, thermal, multi, ctx->axis_z, devphys, act_f64, pc, st); break;
+        case STG_SOLVER_EULER: stg_dispatch_step_euler(a, thermal, multi, ctx->axis_z, devphys, act_f64, pc, st); break;
+        default: stg_dispatch_step_rk45(a, ctx->cfg.thermal != 0, multi, ctx->axis_z_llgs, act_f64, pc, st); break;
     }
     HIP_TRY(hipGetLastError());
     return STG_OK;
@@ -1097,12 +603,6 @@ int stg_device_terms(stg_ctx* ctx, const double* m, const double* J, const doubl
     HIP_TRY(hipGetLastError());
     return STG_OK;
 }
-
-#ifdef STG_PROFILE_LOOP
-int stg_debug_prof(long long* out) {          // experiment builds only
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(stg::g_stg_prof), 16 * sizeof(long long)) == hipSuccess ? 0 : -1;
-}
-#endif
 
 int stg_get_counters(stg_ctx* ctx, uint64_t* out, int32_t reset) {
     if (!ctx || !out) return fail(STG_E_INVALID, "ctx/out is NULL");

@@ -569,11 +569,10 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
     // The loop exists twice (white / Ornstein-Uhlenbeck field), chosen once outside: `ou` is wave-uniform.
     auto run = [&](auto ou_tag) {
     constexpr bool ou = decltype(ou_tag)::value;
-    for (int i = 0;; ++i) {
-      // wave-uniform loop, branch-free body: a lane past its n walks along with its state frozen (see llgs_solve)
-      const bool act = i < n;
-      if (!NSRC::kShared && __ballot(act) == 0ull) break;
-      {
+    // (a counted loop: the compiler's lane-divergent form costs 115 instructions per sub-step, the select-based
+    // wave-uniform form that pays off for RK45 costs 130 here)
+    for (int i = 0; NSRC::kShared || i < n; ++i) {
+      if (i < n) {
         const bool last = (i == n - 1);
         const double kJ2 = last ? kJ2_last : kJ, kJ4 = last ? kJ4_last : kJ;
         const bool on2 = !last || on2_last, on4 = !last || on4_last;
@@ -610,11 +609,10 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
                     __builtin_fma(sixth_dt, __builtin_fma(2.0, f2.y, f1.y) + __builtin_fma(2.0, f3.y, f4.y), m.y),
                     __builtin_fma(sixth_dt, __builtin_fma(2.0, f2.z, f1.z) + __builtin_fma(2.0, f3.z, f4.z), m.z)};
         }
-        const int rs = simple_validate(mn, zr);                            // simple_solver.py:168
-        resets += act ? rs : 0;
-        fail |= act && zr;                                                 // robust_solver.py:192-205
-        m = V3{act ? mn.x : m.x, act ? mn.y : m.y, act ? mn.z : m.z};
-        if (RECORD) { if (act) rec.put(i + 1, last ? T : mul_x((double)(i + 1), dt), m, 0.0); }
+        resets += simple_validate(mn, zr);                                 // simple_solver.py:168
+        fail |= zr;                                                        // robust_solver.py:192-205
+        m = mn;
+        if (RECORD) rec.put(i + 1, last ? T : mul_x((double)(i + 1), dt), m, 0.0);
       }
       if (NSRC::kShared && !ns.chunk_end(i + 1 < n)) break;
     }
@@ -680,7 +678,7 @@ __device__ __forceinline__ double rms3(const V3& a) { return sqrt(dot(a, a)) / 1
 #ifdef STG_PROFILE_LOOP
 // experiment builds only (-DSTG_PROFILE_LOOP): cycles spent in the segments of the RK45 attempt, summed over the attempts
 // of wavefront 0 of workgroup 0, read back with stg_debug_prof()
-__device__ long long g_stg_prof[16];
+static __device__ long long g_stg_prof[16];   // (one copy per translation unit; stg_debug_prof reads the RK45 unit's)
 #define STG_TICK(k) do { const long long now_ = __builtin_readcyclecounter(); prof_[k] += now_ - last_; last_ = now_; } while (0)
 #else
 #define STG_TICK(k) do { } while (0)

@@ -1,0 +1,12 @@
+// stg_step_rk45.hip -- instantiations of the env-step kernel for STG_SOLVER_RK45 (see stg_kernels.hpp)
+#include "stg_kernels.hpp"
+
+void stg_dispatch_step_rk45(const StepArgs& a, bool thermal, bool multi, bool axis_z, int act_f64, bool pc, hipStream_t st) {
+    dispatch_step<STG_SOLVER_RK45>(a, thermal, multi, axis_z, false, act_f64, pc, st);
+}
+
+#ifdef STG_PROFILE_LOOP
+extern "C" int stg_debug_prof(long long* out) {          // experiment builds only (tools/probe_loop_profile.py)
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(stg::g_stg_prof), 16 * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+#endif
