@@ -474,9 +474,16 @@ __device__ __forceinline__ int simple_validate(V3& m, bool& zero_row) {
 #pragma clang fp contract(off)
     zero_row = false;
     const double s = dot(m, m);
+    const double inv = rsqrt_fast(s);           // s = inf (finite m, overflowed norm) -> inv = 0 -> zero row
+    // ordinary case for the whole wavefront: 1e-24 <= |m|^2 <= DBL_MAX implies finite components (a NaN or inf
+    // component makes s NaN or inf) -- the special cases sit behind a wave-uniform branch
+    const bool ordinary = (s >= 1e-24) && (s <= 1.7976931348623157e308);
+    if (__builtin_expect(__ballot(!ordinary) == 0ull, 1)) {
+        m = V3{m.x * inv, m.y * inv, m.z * inv};
+        return 0;
+    }
     // non-finite components, or |m| < 1e-12 (s < 1e-24): the reference's "safe default" [0,0,1]
     if (!finite3(m) || s < 1e-24) { m = V3{0.0, 0.0, 1.0}; return 1; }
-    const double inv = rsqrt_fast(s);           // s = inf (finite m, overflowed norm) -> inv = 0 -> zero row
     m = V3{m.x * inv, m.y * inv, m.z * inv};
     zero_row = isinf(s);
     return 0;
