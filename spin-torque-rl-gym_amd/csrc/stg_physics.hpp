@@ -824,9 +824,11 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
         // the SQUARED norm here); NaN error norms reject (nan < 1 is False) with fmax(0.2, NaN) = 0.2, as in SciPy.
         const bool acc = active && err < 1.0;
         const double r9 = 0.9 * inv_tenth_root(err);
-        double fa = (err <= 3.486784401e-11) ? 10.0 : fmin(10.0, r9);                      // also err == 0
+        // (the clamps also cover the ends of the range: err -> 0 makes r9 huge, inf or -- at exactly 0 -- NaN, and
+        // fmin/fmax return their other operand for a NaN; err -> inf makes it 0 or NaN)
+        double fa = fmin(10.0, r9);
         fa = rejected ? fmin(1.0, fa) : fa;
-        const double fr = (err >= 3405062.8916015625) ? 0.2 : fmax(0.2, r9);
+        const double fr = fmax(0.2, r9);
         h_abs = active ? h_try * (acc ? fa : fr) : h_abs;
         // an accepted attempt advances, records, and does the next step()'s prologue
         t = acc ? t_new : t;

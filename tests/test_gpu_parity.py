@@ -1104,3 +1104,22 @@ def test_schedule_covers_every_env_exactly_once(stg, n):
     for x, y in zip(*outs):
         assert torch.equal(x, y), (n,)
     assert bool((outs[0][3] == 1).all())
+
+
+def test_rk45_zero_error_norm_and_fixed_points(stg):
+    """m along the easy axis with no current is a fixed point: every RK45 error norm is exactly 0 (SciPy: factor =
+    MAX_FACTOR), and the hard axis is an unstable one.  The kernel's clamps must behave at err = 0 as SciPy's do."""
+    from helpers import OracleBackend
+    n = 64
+    m0 = np.tile([0.0, 0.0, 1.0], (n, 1)); m0[1] = [0.0, 0.0, -1.0]; m0[2] = [1.0, 0.0, 0.0]; m0[3] = [0.6, 0.0, 0.8]
+    tgt = np.tile([0.0, 0.0, 1.0], (n, 1))
+    res = []
+    for backend in (None, OracleBackend):
+        env = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(), include_thermal_fluctuations=False, solver="rk45", backend=backend)
+        env.reset(options={"initial_state": m0, "target_state": tgt})
+        a = np.zeros((n, 2), dtype=np.float32); a[:, 1] = 2e-11
+        o, r, te, tr, info = env.step(torch.from_numpy(a))
+        res.append((env.get_state()["m"].cpu().numpy().copy(), info["status"].cpu().numpy().copy()))
+        env.close()
+    assert np.array_equal(res[0][1], res[1][1]) and np.abs(res[0][0] - res[1][0]).max() <= 1e-12
+    assert (res[0][1] == 0).all() and np.array_equal(res[0][0][:, 0], [0.0, 0.0, 1.0])
