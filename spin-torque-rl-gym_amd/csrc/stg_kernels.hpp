@@ -123,7 +123,7 @@ __device__ __forceinline__ const double* class_row(const double* ctab, const uin
 }
 
 __device__ __forceinline__ SimpleK load_simple(const double* r) {
-    return SimpleK{V3{r[C_EX], r[C_EY], r[C_EZ]}, r[C_HK], r[C_MS], r[C_ALPHA], r[C_GEFF], r[C_HS_SIMPLE]};
+    return make_simple(V3{r[C_EX], r[C_EY], r[C_EZ]}, r[C_HK], r[C_MS], r[C_ALPHA], r[C_GEFF], r[C_HS_SIMPLE]);
 }
 __device__ __forceinline__ LlgsK load_llgs(const double* r) {
     return make_llgs(V3{r[C_RX], r[C_RY], r[C_RZ]}, V3{r[C_DX], r[C_DY], r[C_DZ]}, r[C_HK], r[C_HEX], r[C_ALPHA], r[C_GAMMA],
@@ -144,7 +144,7 @@ __device__ __forceinline__ SolveOut run_solver(const V3& m, double J, double T, 
                                                    c.max_attempts, rk, rec, ek, ns, enabled);
     }
     const SimpleK k = load_simple(row);
-    DevTorque dv{0.0, 0.0, V3{0.0, 1.0, 0.0}, k.hk, false};
+    DevTorque dv{0.0, 0.0, V3{0.0, 1.0, 0.0}, k.ghk, false};
     double pol = row[C_POL];
     if (DEVPHYS) {
         // per-lane coefficients of the device-physics torque model (stg_physics.hpp: DevTorque)
@@ -162,7 +162,7 @@ __device__ __forceinline__ SolveOut run_solver(const V3& m, double J, double T, 
             const V3 ref{row[C_REFX], row[C_REFY], row[C_REFZ]};
             const double r = resistance(m, kind, row[C_RP], row[C_RAP], row[C_TMR], ref, row[C_RSERIES]);
             const double keff = vcma_keff(J * r * row[C_AREA], row[C_KU], row[C_VCMA_XI], row[C_VCMA_TD2], row[C_VCMA_VBD]);
-            dv.hk_pulse = (2 * keff) / row[C_MU0MS];
+            dv.ghk_pulse = -row[C_GEFF] * ((2 * keff) / row[C_MU0MS]);
         }
     }
     return simple_solve<SOLVER == STG_SOLVER_EULER ? 1 : 0, THERMAL, RECORD, AXIS_Z, DEVPHYS>(

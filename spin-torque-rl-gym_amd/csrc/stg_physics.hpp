@@ -358,10 +358,17 @@ __device__ __forceinline__ void produce_normals(T* buf, volatile int* alive, int
 }
 
 // ---- per-lane constant sets ----------------------------------------------------------------------
-struct SimpleK {            // A1/A2 constants of this lane's device class
-    V3 e;
-    double hk, ms, alpha, geff, hs;
+struct SimpleK {            // A1/A2 constants of this lane's device class, with -gamma' = -gamma/(1+alpha^2) folded in
+    V3 e;                   // easy axis, normalised
+    double ghk;             // -gamma' * H_k
+    double gdm;             // +gamma' * Ms          (-gamma' times the demagnetising field -Ms m_z z^)
+    double alpha;
+    double ghs;             // -gamma' * Brown strength
 };
+__device__ __forceinline__ SimpleK make_simple(const V3& e, double hk, double ms, double alpha, double geff, double hs) {
+#pragma clang fp contract(off)
+    return SimpleK{e, -geff * hk, geff * ms, alpha, -geff * hs};
+}
 struct LlgsK {              // A6 constants, with -gamma folded in (dm0 = -gamma m x H = m x (-gamma H))
     V3 r;                   // raw easy axis
     V3 gd;                  // -gamma * (-ms * demag_factors)
@@ -378,56 +385,53 @@ __device__ __forceinline__ LlgsK make_llgs(const V3& r, const V3& d, double hk, 
 }
 
 
-// A1 + A2: SimpleLLGSSolver._compute_dmdt with h_applied = 0 (simple_solver.py:297-388), regrouped:
-//   H = c e + d z^ (+ hs z),  c = hk (m.e),  d = -ms m_z
-//   dm/dt = -geff (p + alpha m x p) + aJ m x (m x e),  p = m x H
-//         = -geff [ p + m x (alpha p + kJ t) ],         t = m x e,  kJ = aJ / (-geff)
-// 31 fp64 instructions (T = 0 K) instead of 42 for the literal form; every intermediate stays at or below the
-// magnitude of the reference's own intermediates, so overflow happens at the same sub-step.
+// A1 + A2: SimpleLLGSSolver._compute_dmdt with h_applied = 0 (simple_solver.py:297-388), regrouped.  With
+//   H = hk (m.e) e - Ms m_z z^ (+ hs z),   g' = gamma/(1+alpha^2),   G = -g' H,   t = m x e:
+//   dm/dt = -g' (m x H + alpha m x (m x H)) + aJ m x (m x e)  =  p + m x (alpha p + aJ t),   p = m x G.
+// -g' rides in the constants (ghk, gdm, ghs), so nothing is scaled at the end: 27 fp64 instructions at T = 0 K instead
+// of 42 for the literal form (11 with the easy axis along z); the intermediates are the reference's own g'-scaled
+// quantities, so overflow happens at the same sub-step.
+// ghk: -g' H_k of this stage (a VCMA lane of the device-physics model has a different one while its pulse is on).
 template <bool THERMAL, bool AXIS_Z>
-__device__ __forceinline__ V3 simple_rhs(const V3& m, const SimpleK& k, double hk, double kJ, const V3& z) {
+__device__ __forceinline__ V3 simple_rhs(const V3& m, const SimpleK& k, double ghk, double aJ, const V3& z) {
     // every FMA of the fixed-step path is written out and contraction is off, so all instantiations of this source
     // (one or two wavefronts per workgroup, any launch size) round identically: results do not depend on the partition
 #pragma clang fp contract(off)
     if (AXIS_Z) {
-        // easy axis = +z exactly (every factory default, device_factory.py:129-172): t = (my, -mx, 0), H = (0, 0, hz),
-        // so the products with the axis' zero components drop out -- 14 fp64 instructions at T = 0 K.  (They only
-        // differ from the general form when a factor is already inf/NaN, where both forms end non-finite.)
-        const double hz = __builtin_fma(hk, m.z, -k.ms * m.z);
+        // easy axis = +z exactly (every factory default, device_factory.py:129-172): t = (my, -mx, 0), G = (0, 0, gz),
+        // so the products with the axis' zero components drop out.  (They only differ from the general form when a
+        // factor is already inf/NaN, where both forms end non-finite.)
+        const double gz = (ghk + k.gdm) * m.z;
         V3 p;
         if (THERMAL) {
-            const V3 h{k.hs * z.x, k.hs * z.y, __builtin_fma(k.hs, z.z, hz)};
-            p = cross(m, h);
+            const V3 g{k.ghs * z.x, k.ghs * z.y, __builtin_fma(k.ghs, z.z, gz)};
+            p = cross(m, g);
         } else {
-            p = V3{m.y * hz, -(m.x * hz), 0.0};
+            p = V3{m.y * gz, -(m.x * gz), 0.0};
         }
-        const double wx = __builtin_fma(k.alpha, p.x, kJ * m.y), wy = __builtin_fma(k.alpha, p.y, -(kJ * m.x));
-        V3 r;
+        const double wx = __builtin_fma(k.alpha, p.x, aJ * m.y), wy = __builtin_fma(k.alpha, p.y, -(aJ * m.x));
         if (THERMAL) {
             const double wz = k.alpha * p.z;
-            r = V3{__builtin_fma(m.y, wz, __builtin_fma(-m.z, wy, p.x)), __builtin_fma(m.z, wx, __builtin_fma(-m.x, wz, p.y)),
-                   __builtin_fma(m.x, wy, __builtin_fma(-m.y, wx, p.z))};
-        } else {
-            r = V3{__builtin_fma(-m.z, wy, p.x), __builtin_fma(m.z, wx, p.y), __builtin_fma(m.x, wy, -(m.y * wx))};
+            return V3{__builtin_fma(m.y, wz, __builtin_fma(-m.z, wy, p.x)), __builtin_fma(m.z, wx, __builtin_fma(-m.x, wz, p.y)),
+                      __builtin_fma(m.x, wy, __builtin_fma(-m.y, wx, p.z))};
         }
-        return V3{-k.geff * r.x, -k.geff * r.y, -k.geff * r.z};
+        return V3{__builtin_fma(-m.z, wy, p.x), __builtin_fma(m.z, wx, p.y), __builtin_fma(m.x, wy, -(m.y * wx))};
     }
     const V3 t = cross(m, k.e);
-    const double c = hk * dot(m, k.e);
-    const double d = -k.ms * m.z;
+    const double c = ghk * dot(m, k.e);
+    const double d = k.gdm * m.z;
     V3 p;
     if (THERMAL) {
-        const V3 h{__builtin_fma(k.hs, z.x, c * k.e.x), __builtin_fma(k.hs, z.y, c * k.e.y),
-                   __builtin_fma(k.hs, z.z, __builtin_fma(c, k.e.z, d))};                 // simple_solver.py:384,388
-        p = cross(m, h);
+        const V3 g{__builtin_fma(k.ghs, z.x, c * k.e.x), __builtin_fma(k.ghs, z.y, c * k.e.y),
+                   __builtin_fma(k.ghs, z.z, __builtin_fma(c, k.e.z, d))};                // simple_solver.py:384,388
+        p = cross(m, g);
     } else {
         p = V3{__builtin_fma(c, t.x, d * m.y), __builtin_fma(c, t.y, -(d * m.x)), c * t.z};
     }
-    const V3 w{__builtin_fma(k.alpha, p.x, kJ * t.x), __builtin_fma(k.alpha, p.y, kJ * t.y),
-               __builtin_fma(k.alpha, p.z, kJ * t.z)};
-    const V3 r{__builtin_fma(m.y, w.z, __builtin_fma(-m.z, w.y, p.x)), __builtin_fma(m.z, w.x, __builtin_fma(-m.x, w.z, p.y)),
-               __builtin_fma(m.x, w.y, __builtin_fma(-m.y, w.x, p.z))};
-    return V3{-k.geff * r.x, -k.geff * r.y, -k.geff * r.z};
+    const V3 w{__builtin_fma(k.alpha, p.x, aJ * t.x), __builtin_fma(k.alpha, p.y, aJ * t.y),
+               __builtin_fma(k.alpha, p.z, aJ * t.z)};
+    return V3{__builtin_fma(m.y, w.z, __builtin_fma(-m.z, w.y, p.x)), __builtin_fma(m.z, w.x, __builtin_fma(-m.x, w.z, p.y)),
+              __builtin_fma(m.x, w.y, __builtin_fma(-m.y, w.x, p.z))};
 }
 
 // ---- opt-in device-physics torque model (BASELINE config 4 "divergent torque terms") -------------------
@@ -442,7 +446,7 @@ __device__ __forceinline__ V3 simple_rhs(const V3& m, const SimpleK& k, double h
 struct DevTorque {
     double sdl, sfl;      // tau_dl J/(ms V), tau_fl J/(ms V) for SOT lanes, else 0
     V3 sigma;
-    double hk_pulse;      // H_k while the pulse is on (VCMA: from K_eff(V)); = hk for other types
+    double ghk_pulse;     // -gamma' H_k while the pulse is on (VCMA: from K_eff(V)); = ghk for other types
     bool any_sot;         // wave-uniform
 };
 
@@ -454,11 +458,11 @@ __device__ __forceinline__ double vcma_keff(double volt, double ku, double xi, d
 }
 
 template <bool THERMAL, bool AXIS_Z, bool DEVPHYS>
-__device__ __forceinline__ V3 simple_stage(const V3& m, const SimpleK& k, double kJ, const V3& z, const DevTorque& dv,
+__device__ __forceinline__ V3 simple_stage(const V3& m, const SimpleK& k, double aJ, const V3& z, const DevTorque& dv,
                                            bool on) {
 #pragma clang fp contract(off)
-    if (!DEVPHYS) return simple_rhs<THERMAL, AXIS_Z>(m, k, k.hk, kJ, z);
-    V3 f = simple_rhs<THERMAL, AXIS_Z>(m, k, on ? dv.hk_pulse : k.hk, kJ, z);
+    if (!DEVPHYS) return simple_rhs<THERMAL, AXIS_Z>(m, k, k.ghk, aJ, z);
+    V3 f = simple_rhs<THERMAL, AXIS_Z>(m, k, on ? dv.ghk_pulse : k.ghk, aJ, z);
     if (dv.any_sot) {
         const double a = on ? dv.sdl : 0.0, b = on ? dv.sfl : 0.0;
         const V3 sxm = cross(dv.sigma, m);
@@ -549,7 +553,7 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
     const double half_dt = 0.5 * dt, sixth_dt = dt / 6.0;
     const bool useJ = fabs(J) > 1e-12;                                     // simple_solver.py:326
     const double aJ = useJ ? (pol * J) / msv : 0.0;                        // simple_solver.py:330
-    const double kJ = aJ / (-k.geff);                                      // see simple_rhs
+    const double kJ = aJ;                                                  // (the RHS takes a_J itself, see simple_rhs)
     // Stage times are t_i = i*dt (np.linspace), t_i + dt/2, t_i + dt and the pulse is on while t <= T
     // (spin_torque_env.py:442-443).  For i <= n-2 every stage time is below T by at least dt/2; only the last
     // sub-step's k2/k3/k4 stages can land an ulp beyond T and see J = 0, so only that one is tested,
