@@ -477,6 +477,15 @@ __device__ __forceinline__ V3 simple_stage(const V3& m, const SimpleK& k, double
 __device__ __forceinline__ int simple_validate(V3& m, bool& zero_row) {
 #pragma clang fp contract(off)
     zero_row = false;
+    // First tier (every RK4 sub-step in practice): |m|^2 within 2^-10 of 1 for the whole wavefront -- a step of a
+    // unit vector leaves it there -- so 1/|m| = (1 + e)^-1/2 comes from four Horner FMAs (truncation 0.25 |e|^5 < 2.3e-16)
+    // instead of v_rsq_f64 and its correction.
+    const double e = __builtin_fma(m.z, m.z, __builtin_fma(m.y, m.y, __builtin_fma(m.x, m.x, -1.0)));
+    if (__builtin_expect(__ballot(!(fabs(e) < 0.0009765625)) == 0ull, 1)) {
+        const double inv1 = __builtin_fma(e, __builtin_fma(e, __builtin_fma(e, __builtin_fma(e, 0.2734375, -0.3125), 0.375), -0.5), 1.0);
+        m = V3{m.x * inv1, m.y * inv1, m.z * inv1};
+        return 0;
+    }
     const double s = dot(m, m);
     const double inv = rsqrt_fast(s);           // s = inf (finite m, overflowed norm) -> inv = 0 -> zero row
     // ordinary case for the whole wavefront: 1e-24 <= |m|^2 <= DBL_MAX implies finite components (a NaN or inf
@@ -580,11 +589,11 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
     // The loop exists twice (white / Ornstein-Uhlenbeck field), chosen once outside: `ou` is wave-uniform.
     auto run = [&](auto ou_tag) {
     constexpr bool ou = decltype(ou_tag)::value;
-    // (a counted loop: the compiler's lane-divergent form costs 115 instructions per sub-step, the select-based
-    // wave-uniform form that pays off for RK45 costs 130 here)
-    for (int i = 0; NSRC::kShared || i < n; ++i) {
-      if (i < n) {
-        const bool last = (i == n - 1);
+    // one sub-step; WHICH: 0 = not the last one (pulse on in every stage), 1 = the last one (stage gates of H4),
+    // 2 = decided at run time (SharedNormals: every sub-step is a chunk of the wave-uniform loop)
+    auto substep = [&](int i, auto which_tag) {
+        constexpr int WHICH = decltype(which_tag)::value;
+        const bool last = WHICH == 2 ? (i == n - 1) : (WHICH == 1);
         const double kJ2 = last ? kJ2_last : kJ, kJ4 = last ? kJ4_last : kJ;
         const bool on2 = !last || on2_last, on4 = !last || on4_last;
         V3 mn;
@@ -624,8 +633,16 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
         fail |= zr;                                                        // robust_solver.py:192-205
         m = mn;
         if (RECORD) rec.put(i + 1, last ? T : mul_x((double)(i + 1), dt), m, 0.0);
-      }
-      if (NSRC::kShared && !ns.chunk_end(i + 1 < n)) break;
+    };
+    if (NSRC::kShared) {
+        for (int i = 0;; ++i) {
+            if (i < n) substep(i, std::integral_constant<int, 2>{});
+            if (!ns.chunk_end(i + 1 < n)) break;
+        }
+    } else {
+        // a counted, lane-divergent loop over the first n-1 sub-steps, then the last one with the stage gates (n >= 10)
+        for (int i = 0; i < n - 1; ++i) substep(i, std::integral_constant<int, 0>{});
+        substep(n - 1, std::integral_constant<int, 1>{});
     }
     };
     if (THERMAL && ou_sel) run(std::true_type{}); else run(std::false_type{});
