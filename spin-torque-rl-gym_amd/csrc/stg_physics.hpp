@@ -236,10 +236,22 @@ struct NormalStream {
     __device__ __forceinline__ void pair(float& a, float& b) {
         // the two mantissa-trick subtractions and the two final products go through packed fp32 (v_pk_add_f32 /
         // v_pk_mul_f32: one instruction for both lanes of the pair, same IEEE results)
+        float t, c, s_;
+        pair_head(t, c, s_);
+        finish_pair(t, c, s_, a, b);
+    }
+    // the same pair in two halves: pair() == finish_pair(pair_head(...)); a producer wavefront can hand over the head
+    // (t = -2 ln u0, cos, sin) and leave the square root and the products to the integrating wavefront
+    __device__ __forceinline__ void pair_head(float& t, float& c, float& s_) {
         f32x2 u{__uint_as_float(__builtin_amdgcn_alignbit(0x7fu, next(), 9u)), __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, next(), 9u))};
         u = u - f32x2{0.99999994f, 0.99999994f};
-        const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u.x));   // sqrt(-2 ln u0), raw v_sqrt_f32
-        const f32x2 cs = f32x2{__builtin_amdgcn_cosf(u.y), __builtin_amdgcn_sinf(u.y)} * f32x2{r, r};
+        t = -1.3862943611198906f * __builtin_amdgcn_logf(u.x);
+        c = __builtin_amdgcn_cosf(u.y);
+        s_ = __builtin_amdgcn_sinf(u.y);
+    }
+    static __device__ __forceinline__ void finish_pair(float t, float c, float s_, float& a, float& b) {
+        const float r = __builtin_amdgcn_sqrtf(t);
+        const f32x2 cs = f32x2{c, s_} * f32x2{r, r};
         a = cs.x;
         b = cs.y;
     }
@@ -480,14 +492,17 @@ __device__ __forceinline__ int simple_validate(V3& m, bool& zero_row) {
     // First tier (every RK4 sub-step in practice): |m|^2 within 2^-10 of 1 for the whole wavefront -- a step of a
     // unit vector leaves it there -- so 1/|m| = (1 + e)^-1/2 comes from four Horner FMAs (truncation 0.25 |e|^5 < 2.3e-16)
     // instead of v_rsq_f64 and its correction.
+    // A lane's arithmetic must not depend on its wavefront-mates (the lane schedule changes them from run to run): the
+    // wave-uniform tests below only skip work, a lane near |m| = 1 uses the series on either path.
     const double e = __builtin_fma(m.z, m.z, __builtin_fma(m.y, m.y, __builtin_fma(m.x, m.x, -1.0)));
-    if (__builtin_expect(__ballot(!(fabs(e) < 0.0009765625)) == 0ull, 1)) {
-        const double inv1 = __builtin_fma(e, __builtin_fma(e, __builtin_fma(e, __builtin_fma(e, 0.2734375, -0.3125), 0.375), -0.5), 1.0);
+    const bool near1 = fabs(e) < 0.0009765625;
+    const double inv1 = __builtin_fma(e, __builtin_fma(e, __builtin_fma(e, __builtin_fma(e, 0.2734375, -0.3125), 0.375), -0.5), 1.0);
+    if (__builtin_expect(__ballot(!near1) == 0ull, 1)) {
         m = V3{m.x * inv1, m.y * inv1, m.z * inv1};
         return 0;
     }
     const double s = dot(m, m);
-    const double inv = rsqrt_fast(s);           // s = inf (finite m, overflowed norm) -> inv = 0 -> zero row
+    const double inv = near1 ? inv1 : rsqrt_fast(s);   // s = inf (finite m, overflowed norm) -> inv = 0 -> zero row
     // ordinary case for the whole wavefront: 1e-24 <= |m|^2 <= DBL_MAX implies finite components (a NaN or inf
     // component makes s NaN or inf) -- the special cases sit behind a wave-uniform branch
     const bool ordinary = (s >= 1e-24) && (s <= 1.7976931348623157e308);

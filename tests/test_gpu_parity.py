@@ -891,6 +891,10 @@ def test_ornstein_uhlenbeck_noise_model_vs_oracle(stg, solver):
             res.append(out)
             env.close()
         for k in range(2):
+            if not np.array_equal(res[0][k][0], res[1][k][0]):
+                dd = np.abs(res[0][k][0] - res[1][k][0]); bad = np.nonzero(dd.max(axis=0))[0]
+                print("DIAG", solver, multi, k, "n_bad", len(bad), "lanes", bad[:16], "max", dd.max(), "oracle diff off/on",
+                      np.abs(res[0][k][0] - res[2][k][0]).max(), np.abs(res[1][k][0] - res[2][k][0]).max())
             assert np.array_equal(res[0][k][0], res[1][k][0])                       # wave_spec on/off: bit-identical
             assert np.array_equal(res[0][k][1], res[2][k][1])
             d = np.abs(res[0][k][0] - res[2][k][0]).max()
