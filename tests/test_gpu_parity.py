@@ -1127,3 +1127,50 @@ def test_rk45_zero_error_norm_and_fixed_points(stg):
         env.close()
     assert np.array_equal(res[0][1], res[1][1]) and np.abs(res[0][0] - res[1][0]).max() <= 1e-12
     assert (res[0][1] == 0).all() and np.array_equal(res[0][0][:, 0], [0.0, 0.0, 1.0])
+
+
+@pytest.mark.parametrize("solver", ["euler", "rk4", "rk45"])
+def test_results_do_not_depend_on_wavefront_composition(stg, solver):
+    """The tile sort ranks the envs of one duration bucket in the order their LDS atomics arrive, so which envs share a
+    wavefront varies from run to run.  A lane's arithmetic must not depend on its wavefront-mates (the wave-uniform fast
+    paths may only skip work): repeated runs of the same step -- many envs per bucket, short and long pulses mixed so
+    that the fast and the general normalisation meet in one wavefront -- must agree bit for bit, thermal on and off."""
+    n = 8192
+    rng = np.random.default_rng(5)
+    vol = 9.7e-6 if solver == "rk45" else 8.75e-11
+    a = np.empty((n, 2), dtype=np.float32)
+    a[:, 0] = rng.choice([0.0, 1e6, -2e6], n)
+    a[:, 1] = rng.choice([1e-12, 2e-11, 1.5e-10], n)             # three buckets, thousands of envs each
+    for thermal in (False, True):
+        ref = None
+        for rep in range(5):
+            env = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(volume=vol), include_thermal_fluctuations=thermal,
+                                       solver=solver, seed=3)
+            env.reset(seed=9)
+            o, r, te, tr, info = env.step(torch.from_numpy(a))
+            cur = (env.get_state()["m"].clone(), info["reward_f64"].clone(), o.clone())
+            env.close()
+            if ref is None:
+                ref = cur
+            else:
+                assert all(torch.equal(x, y) for x, y in zip(ref, cur)), (solver, thermal, rep)
+    if solver == "rk45":
+        return
+    # strong-noise regime: |m|^2 after a sub-step scatters around the threshold of the fast normalisation, so most
+    # wavefronts mix both paths whatever the sort does
+    n = 4096
+    a = np.zeros((n, 2), dtype=np.float32)
+    a[:, 1] = rng.uniform(1e-10, 3e-10, n).astype(np.float32)
+    for noise in ("white", "ou"):
+        ref = None
+        for rep in range(6):
+            env = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(volume=1e-27), include_thermal_fluctuations=True,
+                                       solver=solver, seed=13, noise_model=noise, correlation_time=3e-12)
+            env.reset(seed=9)
+            env.step(torch.from_numpy(a))
+            cur = env.get_state()["m"].clone()
+            env.close()
+            if ref is None:
+                ref = cur
+            else:
+                assert torch.equal(ref, cur), (solver, noise, rep, int((ref != cur).any(dim=0).sum()))
