@@ -301,6 +301,8 @@ def roofline(meas, n_local, steps, solver, mixed=False, thermal=None, sorted_sch
             "algorithmic_bytes": bytes_per_launch,
             "kernel": "stg_step_kernel", "kernel_ms_avg": round(meas["kernel_ms_avg"], 4),
             "flops_per_work_unit": flops_per_unit,
+            "flops_basis": "reference formulation (SURVEY 8d); the kernels fold constants and execute fewer, so frac is "
+                           "a work-equivalent rate, not issue-slot utilisation (DESIGN.md section 5)",
             "work_units_per_env_step": round(meas["work_units"] / max(meas["env_steps"], 1), 2),
             "hbm": {"achieved": round(gbs, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 7),
                     "bytes_per_env_step": BYTES_PER_ENV_STEP_MIXED if mixed else BYTES_PER_ENV_STEP}}
