@@ -751,9 +751,15 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
     // (J while t <= T) can only close for stage times of the form fl(t + h) on the step that is clamped to end at T:
     // every other stage time is fl(t + fl(c h)) with c <= 8/9, hence <= t_new <= T by monotonic rounding, and an
     // unclamped fl(t + h) is within an ulp of t_new < T.  So only k6 / f_new of an attempt test the gate (`on`).
-    auto fun = [&](const V3& y, bool even, bool on) -> V3 {
-        V3 ht = zero;
-        if (THERMAL) ht = NSRC::kScaled ? ns.draw(even) : scale3(k.ghs, ns.draw(even));
+    // `draw` fetches the thermal field of one RHS call (already times -gamma), `fun` evaluates the call.  They are
+    // separate so that the loop can fetch call j+1's field before it evaluates call j: with the shared source a draw
+    // is three LDS reads, and issued at the point of use each of them stalls the lone integrating wavefront for the
+    // LDS latency (six stalls per attempt).
+    auto draw = [&](bool even) -> V3 {
+        if (!THERMAL) return zero;
+        return NSRC::kScaled ? ns.draw(even) : scale3(k.ghs, ns.draw(even));
+    };
+    auto fun = [&](const V3& y, const V3& ht, bool on) -> V3 {
         return llgs_rhs<THERMAL, AXIS_Z>(y, k, on ? bJ : 0.0, on ? bpJ : 0.0, ht);
     };
     const double n0 = rsqrt_fast(dot(m0, m0));                              // llgs_solver.py:76
@@ -769,7 +775,7 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
         ++npts;
     };
     if (RECORD) emit(); else ++npts;
-    V3 f = fun(y, true, true);                             // t = 0 <= T
+    V3 f = fun(y, draw(true), true);                       // t = 0 <= T
     double h_abs;
     {   // select_initial_step (common.py:68-134), order = error_estimator_order = 4
         // (quotients by reciprocal-multiply, ~1 ulp: these norms only seed the first step size)
@@ -780,7 +786,7 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
         double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : (0.01 * d0) * rcp_fast(d1);
         h0 = fmin(h0, T);
         const V3 y1{y.x + h0 * f.x, y.y + h0 * f.y, y.z + h0 * f.z};
-        const V3 f1 = fun(y1, false, true);                // t + h0 = h0 <= T (h0 = min(h0, T))
+        const V3 f1 = fun(y1, draw(false), true);          // t + h0 = h0 <= T (h0 = min(h0, T))
         const double d2 = rms3(V3{(f1.x - f.x) * isc.x, (f1.y - f.y) * isc.y, (f1.z - f.z) * isc.z}) * rcp_fast(h0);
         const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : fifth_root(0.01 * rcp_fast(fmax(d1, d2)));
         h_abs = fmin(fmin(100.0 * h0, h1), fmin(T, max_step));
@@ -824,26 +830,33 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
         // rk_step (rk.py:14-70); the one stage time that can pass T is formed without contraction
         const bool on_end = add_x(t, h) <= T;
         const V3 k1 = f;
-        const V3 k2 = fun(V3{y.x + (k1.x * A21) * h, y.y + (k1.y * A21) * h, y.z + (k1.z * A21) * h}, true, true);
+        // normal-stream phases alternate per call (k2: even, k3: odd, ...); each field is fetched one call ahead
+        const V3 z2 = draw(true);
+        const V3 z3 = draw(false);
+        const V3 k2 = fun(V3{y.x + (k1.x * A21) * h, y.y + (k1.y * A21) * h, y.z + (k1.z * A21) * h}, z2, true);
         STG_TICK(1);
+        const V3 z4 = draw(true);
         const V3 k3 = fun(V3{y.x + (k1.x * A31 + k2.x * A32) * h, y.y + (k1.y * A31 + k2.y * A32) * h,
-                             y.z + (k1.z * A31 + k2.z * A32) * h}, false, true);
+                             y.z + (k1.z * A31 + k2.z * A32) * h}, z3, true);
         STG_TICK(2);
+        const V3 z5 = draw(false);
         const V3 k4 = fun(V3{y.x + (k1.x * A41 + k2.x * A42 + k3.x * A43) * h, y.y + (k1.y * A41 + k2.y * A42 + k3.y * A43) * h,
-                             y.z + (k1.z * A41 + k2.z * A42 + k3.z * A43) * h}, true, true);
+                             y.z + (k1.z * A41 + k2.z * A42 + k3.z * A43) * h}, z4, true);
         STG_TICK(3);
+        const V3 z6 = draw(true);
         const V3 k5 = fun(V3{y.x + (k1.x * A51 + k2.x * A52 + k3.x * A53 + k4.x * A54) * h,
                              y.y + (k1.y * A51 + k2.y * A52 + k3.y * A53 + k4.y * A54) * h,
-                             y.z + (k1.z * A51 + k2.z * A52 + k3.z * A53 + k4.z * A54) * h}, false, true);
+                             y.z + (k1.z * A51 + k2.z * A52 + k3.z * A53 + k4.z * A54) * h}, z5, true);
         STG_TICK(4);
+        const V3 z7 = draw(false);
         const V3 k6 = fun(V3{y.x + (k1.x * A61 + k2.x * A62 + k3.x * A63 + k4.x * A64 + k5.x * A65) * h,
                              y.y + (k1.y * A61 + k2.y * A62 + k3.y * A63 + k4.y * A64 + k5.y * A65) * h,
-                             y.z + (k1.z * A61 + k2.z * A62 + k3.z * A63 + k4.z * A64 + k5.z * A65) * h}, true, on_end);
+                             y.z + (k1.z * A61 + k2.z * A62 + k3.z * A63 + k4.z * A64 + k5.z * A65) * h}, z6, on_end);
         STG_TICK(5);
         const V3 y_new{y.x + h * (k1.x * B1 + k3.x * B3 + k4.x * B4 + k5.x * B5 + k6.x * B6),
                        y.y + h * (k1.y * B1 + k3.y * B3 + k4.y * B4 + k5.y * B5 + k6.y * B6),
                        y.z + h * (k1.z * B1 + k3.z * B3 + k4.z * B4 + k5.z * B5 + k6.z * B6)};
-        const V3 f_new = fun(y_new, false, on_end);
+        const V3 f_new = fun(y_new, z7, on_end);
         STG_TICK(6);
         const V3 ev{(k1.x * E1 + k3.x * E3 + k4.x * E4 + k5.x * E5 + k6.x * E6 + f_new.x * E7) * h,
                     (k1.y * E1 + k3.y * E3 + k4.y * E4 + k5.y * E5 + k6.y * E6 + f_new.y * E7) * h,

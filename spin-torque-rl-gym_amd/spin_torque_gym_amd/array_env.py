@@ -18,10 +18,10 @@ import torch
 
 from . import _lib
 from .devices import DeviceFactory, flatten_params
-from .envs import _EnvBase, _box, _np_random
+from .envs import _EnvBase, _box, _np_random, _spaces
 
 ACTION_MODES = {"individual": 0, "row": 1, "column": 2, "global": 3}
-OBS_MODES = {"array": 0, "vector": 1}
+OBS_MODES = {"array": 0, "vector": 1, "dict": 1}      # 'dict' regroups the vector observation on the host side
 
 
 def compute_coupling_matrix(n_rows: int, n_cols: int, coupling_type: str = "dipolar", coupling_strength: float = 0.1):
@@ -135,7 +135,8 @@ class HipArrayBackend:
 
 class SpinTorqueArrayVecEnv:
     """N parallel SpinTorqueArray-v0 environments.  Observations come back as [N, obs_dim] views ('array' mode:
-    reshape to [N, rows, cols, 6]); actions are [N, 3] ([index, J, T]) or [N, 2] in 'global' mode."""
+    reshape to [N, rows, cols, 6]; 'dict' mode: the reference's five fields (array_env.py:569-578) as tensors with a
+    leading N); actions are [N, 3] ([index, J, T]) or [N, 2] in 'global' mode."""
 
     def __init__(self, num_envs: int, array_size: Tuple[int, int] = (4, 4), device_type: str = "stt_mram",
                  device_params: Optional[Dict[str, Any]] = None, target_pattern: Optional[np.ndarray] = None,
@@ -147,7 +148,7 @@ class SpinTorqueArrayVecEnv:
         if action_mode not in ACTION_MODES:
             raise ValueError(f"Unknown action mode: {action_mode}")
         if observation_mode not in OBS_MODES:
-            raise ValueError(f"Unknown observation mode: {observation_mode} (the GPU path implements 'array' and 'vector')")
+            raise ValueError(f"Unknown observation mode: {observation_mode}")
         self.num_envs = int(num_envs)
         self.array_size = tuple(array_size)
         self.n_rows, self.n_cols = self.array_size
@@ -197,13 +198,27 @@ class SpinTorqueArrayVecEnv:
         obs = self.backend.reset(None if mask is None else torch.as_tensor(mask).to(torch.uint8),
                                  self._soa(options.get("initial_pattern")), self._soa(target), dev_seed)
         self._needs_reset = False
-        return obs.t(), {}
+        return self._shape_obs(obs), {}
+
+    def _shape_obs(self, obs):
+        """[obs_dim, N] kernel output -> what the observation mode promises."""
+        if self.observation_mode != "dict":
+            return obs.t()
+        # array_env.py:569-578: the vector observation's pattern/target/similarity entries, plus the raw step budget and
+        # energy (not the vector mode's normalised ones) from the device state
+        n3 = self.n_devices * 3
+        st = self.backend.get_state()
+        shape = (self.num_envs, self.n_rows, self.n_cols, 3)
+        return {"current_pattern": obs[:n3].t().reshape(shape), "target_pattern": obs[n3:2 * n3].t().reshape(shape),
+                "pattern_similarity": obs[2 * n3:2 * n3 + 1].t(),
+                "steps_remaining": (int(self.cfg.max_steps) - st["step_count"].to(torch.int64)).unsqueeze(1),
+                "total_energy": st["total_energy"].to(torch.float32).unsqueeze(1)}
 
     def step(self, actions):
         if self._needs_reset:
             raise RuntimeError("Environment must be reset before calling step")
         obs, rew, rew64, term, trunc = self.backend.step(torch.as_tensor(actions).t())
-        return obs.t(), rew, term.bool(), trunc.bool(), {"reward_f64": rew64, "energy": self.backend.energy}
+        return self._shape_obs(obs), rew, term.bool(), trunc.bool(), {"reward_f64": rew64, "energy": self.backend.energy}
 
     def get_state(self):
         return self.backend.get_state()
@@ -246,9 +261,17 @@ class SpinTorqueArrayEnv(_EnvBase):
             self.action_space = _box([-max_current, 0.0], [max_current, max_duration], dtype=np.float32)
         else:
             self.action_space = _box([0.0, -max_current, 0.0], [hi[action_mode], max_current, max_duration], dtype=np.float32)
-        shape = (self.n_rows, self.n_cols, 6) if observation_mode == "array" else (self.n_devices * 6 + 4,)
-        self.observation_space = _box(-1.0 if observation_mode == "array" else -np.inf,
-                                      1.0 if observation_mode == "array" else np.inf, shape=shape, dtype=np.float32)
+        if observation_mode == "dict":                                              # array_env.py:273-287
+            pat = (self.n_rows, self.n_cols, 3)
+            fields = {"current_pattern": _box(-1.0, 1.0, shape=pat), "target_pattern": _box(-1.0, 1.0, shape=pat),
+                      "pattern_similarity": _box(0.0, 1.0, shape=(1,)),
+                      "steps_remaining": _box(0, max_steps, shape=(1,), dtype=np.int64),
+                      "total_energy": _box(0.0, np.inf, shape=(1,))}
+            self.observation_space = _spaces.Dict(fields) if _spaces is not None else fields
+        else:
+            shape = (self.n_rows, self.n_cols, 6) if observation_mode == "array" else (self.n_devices * 6 + 4,)
+            self.observation_space = _box(-1.0 if observation_mode == "array" else -np.inf,
+                                          1.0 if observation_mode == "array" else np.inf, shape=shape, dtype=np.float32)
         self._np_random, _ = _np_random(seed)
         self.current_pattern = None
         self.step_count, self.total_energy = 0, 0.0
@@ -258,8 +281,14 @@ class SpinTorqueArrayEnv(_EnvBase):
         self._np_random, s = _np_random(seed)
         return [s]
 
-    def _shape_obs(self, obs_row):
-        o = obs_row.cpu().numpy().copy()
+    def _shape_obs(self, obs):
+        if self.observation_mode == "dict":                                         # array_env.py:569-578
+            return {"current_pattern": self.current_pattern.astype(np.float32),
+                    "target_pattern": self.target_pattern.astype(np.float32),
+                    "pattern_similarity": np.array([self._similarity()], dtype=np.float32),
+                    "steps_remaining": np.array([self.max_steps - self.step_count], dtype=int),
+                    "total_energy": np.array([self.total_energy], dtype=np.float32)}
+        o = obs[0].cpu().numpy().copy()
         return o.reshape(self.n_rows, self.n_cols, 6) if self.observation_mode == "array" else o
 
     def _pull(self):
@@ -289,7 +318,7 @@ class SpinTorqueArrayEnv(_EnvBase):
             self.target_pattern = np.array(options["target_pattern"], dtype=np.float64)
         obs, _ = self._vec.reset(options={"initial_pattern": init, "target_pattern": self.target_pattern})
         self._pull()
-        return self._shape_obs(obs[0]), self._get_info()
+        return self._shape_obs(obs), self._get_info()
 
     def step(self, action):
         if self.current_pattern is None:
@@ -320,7 +349,7 @@ class SpinTorqueArrayEnv(_EnvBase):
         info.update({"energy_consumed": energy, "affected_devices": affected, "current_density": J, "pulse_duration": T,
                      "is_success": bool(term[0]), "step_energy": energy, "pattern_improvement": sim - prev_similarity,
                      "pattern_similarity": sim})
-        return self._shape_obs(obs[0]), reward, bool(term[0]), bool(trunc[0]), info
+        return self._shape_obs(obs), reward, bool(term[0]), bool(trunc[0]), info
 
     def _get_info(self):
         sim = self._similarity()

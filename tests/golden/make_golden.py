@@ -574,7 +574,30 @@ def G16():
     save("G16_device_helpers", **out)
 
 
-ALL = dict(G16=G16, G15=G15, G14=G14, G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11, G12=G12, G13=G13)
+def G17():
+    """array_env, observation_mode='dict' (envs/array_env.py:273-287,569-578): one episode, every field of the dict."""
+    from spin_torque_gym.envs.array_env import SpinTorqueArrayEnv
+    rng = np.random.default_rng(1717)
+    env = SpinTorqueArrayEnv(array_size=(2, 3), action_mode="individual", observation_mode="dict", max_steps=5,
+                             coupling_type="dipolar", coupling_strength=0.2)
+    actions = [(rng.uniform(-0.5, 5.5), rng.uniform(-2e6, 2e6), rng.uniform(1e-10, 2e-9)) for _ in range(6)]
+    keys = ("current_pattern", "target_pattern", "pattern_similarity", "steps_remaining", "total_energy")
+    obs, _ = env.reset(seed=17)
+    rec = {k: [np.asarray(obs[k]).copy()] for k in keys}
+    rec.update(reward=[], terminated=[], truncated=[])
+    for a in actions:
+        obs, r, te, tr, info = env.step(np.array(a, dtype=np.float32))
+        for k in keys:
+            rec[k].append(np.asarray(obs[k]).copy())
+        rec["reward"].append(r); rec["terminated"].append(te); rec["truncated"].append(tr)
+    out = {k: np.array(v) for k, v in rec.items()}
+    out["actions"] = np.array(actions, dtype=np.float32)
+    out["dtypes"] = np.array([str(np.asarray(obs[k]).dtype) for k in keys])
+    print("    G17 dict episode:", {k: out[k].shape for k in keys}, list(out["dtypes"]))
+    save("G17_array_dict", **out)
+
+
+ALL = dict(G17=G17, G16=G16, G15=G15, G14=G14, G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11, G12=G12, G13=G13)
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

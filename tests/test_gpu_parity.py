@@ -759,6 +759,30 @@ def test_array_env_vs_golden_g13(stg, golden):
     print("array env worst |dm| vs reference =", worst)
 
 
+def test_array_env_dict_observation(stg, golden):
+    """observation_mode='dict': the facade against the recorded reference episode (G17), and the vector env's dict of
+    tensors against its own 'vector' observation and device state."""
+    from test_host_logic import _check_dict_episode_g17
+    _check_dict_episode_g17(stg, golden, None, 1e-7)
+    n = 256
+    envs = {m: stg.SpinTorqueArrayVecEnv(n, (3, 4), observation_mode=m, max_steps=7, seed=5) for m in ("dict", "vector")}
+    a = torch.zeros((n, 3), dtype=torch.float32)
+    a[:, 0] = torch.arange(n) % 12; a[:, 1] = 1.5e6; a[:, 2] = 1e-9
+    od, _ = envs["dict"].reset(seed=1)
+    ov, _ = envs["vector"].reset(seed=1)
+    for _ in range(2):
+        od, rd, *_ = envs["dict"].step(a)
+        ov, rv, *_ = envs["vector"].step(a)
+    assert od["current_pattern"].shape == (n, 3, 4, 3) and od["steps_remaining"].dtype == torch.int64
+    assert torch.equal(od["current_pattern"].reshape(n, -1), ov[:, :36]) and torch.equal(od["target_pattern"].reshape(n, -1), ov[:, 36:72])
+    assert torch.equal(od["pattern_similarity"][:, 0], ov[:, 72]) and torch.equal(rd, rv)
+    st = envs["dict"].get_state()
+    assert torch.equal(od["steps_remaining"][:, 0], 7 - st["step_count"].to(torch.int64)) and int(od["steps_remaining"][0, 0]) == 5
+    assert torch.equal(od["total_energy"][:, 0], st["total_energy"].to(torch.float32)) and float(od["total_energy"].min()) > 0
+    for e in envs.values():
+        e.close()
+
+
 @pytest.mark.parametrize("mode", ["individual", "row", "column", "global"])
 def test_array_vec_env_vs_oracle(stg, mode):
     from helpers import OracleArrayBackend

@@ -254,6 +254,40 @@ def test_array_env_facade_vs_golden_g13(stg, golden):
         env.step(np.array([np.nan, 1e6, 1e-9], dtype=np.float32))
 
 
+def _check_dict_episode_g17(stg, golden, backend, m_tol):
+    """observation_mode='dict' of the array env against the recorded reference episode (golden G17)."""
+    g = golden("G17_array_dict")
+    env = stg.SpinTorqueArrayEnv(array_size=(2, 3), action_mode="individual", observation_mode="dict", max_steps=5,
+                                 coupling_type="dipolar", coupling_strength=0.2, backend=backend)
+    keys = ("current_pattern", "target_pattern", "pattern_similarity", "steps_remaining", "total_energy")
+    assert set(getattr(env.observation_space, "spaces", env.observation_space).keys()) == set(keys)
+
+    def check(obs, j):
+        assert set(obs.keys()) == set(keys)
+        for k, dt in zip(keys, g["dtypes"]):
+            assert obs[k].dtype == np.dtype(str(dt)) and obs[k].shape == g[k][j].shape, (k, j)
+        assert np.abs(obs["current_pattern"] - g["current_pattern"][j]).max() <= m_tol, j
+        assert np.array_equal(obs["target_pattern"], g["target_pattern"][j])
+        assert abs(float(obs["pattern_similarity"][0]) - float(g["pattern_similarity"][j][0])) <= max(m_tol, 1e-7)
+        assert int(obs["steps_remaining"][0]) == int(g["steps_remaining"][j][0])
+        e = float(g["total_energy"][j][0])
+        assert abs(float(obs["total_energy"][0]) - e) <= 2e-7 * abs(e), j
+
+    obs, _ = env.reset(seed=17)
+    check(obs, 0)
+    for j, a in enumerate(g["actions"]):
+        obs, r, te, tr, _ = env.step(a)
+        check(obs, j + 1)
+        assert abs(r - g["reward"][j]) <= 1e-9 * max(1.0, abs(g["reward"][j]))
+        assert te == bool(g["terminated"][j]) and tr == bool(g["truncated"][j])
+    env.close()
+
+
+def test_array_env_dict_observation_vs_golden_g17(stg, golden):
+    from helpers import OracleArrayBackend
+    _check_dict_episode_g17(stg, golden, OracleArrayBackend, 1e-7)
+
+
 def test_device_class_analysis_helpers_vs_golden_g16(stg, golden):
     """Analysis helpers of the SOT / VCMA device classes (host closed forms): power, switching thresholds, energy
     barriers, switching-time and leakage estimates against the reference classes' outputs (golden G16)."""
