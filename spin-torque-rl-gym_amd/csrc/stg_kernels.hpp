@@ -303,9 +303,16 @@ __global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR st
     // (double), the fixed-step solvers raw normals (float)
     constexpr bool FIELD = SOLVER == STG_SOLVER_RK45;
     using NT = typename std::conditional<FIELD, double, float>::type;
-    constexpr int RING = 2 * SHARED_CHUNK_MAX * 64;
-    __shared__ NT s_norm[PC ? WGW * RING : 1];
-    __shared__ int s_alive[2 * WGW], s_go[2 * WGW];
+    // how the integrating and the producing wavefront keep in step (stg_physics.hpp, SharedNormalsT), by measurement
+    // at 4096 and 65 536 envs: RK4 by handshake words with a ring of 4 chunks (8-12 % faster than a barrier per
+    // sub-step), RK45 and Euler by one s_barrier per chunk with a ring of 2 (the words are 5-10 % slower there: RK45's
+    // producer has slack and parks at the barrier for free, Euler's chunk is too short to pay for the polling)
+    constexpr bool BARRIER = SOLVER != STG_SOLVER_RK4;
+    constexpr int DEPTH = BARRIER ? 2 : 4;
+    constexpr int RING = DEPTH * SHARED_CHUNK_MAX * 64;
+    static_assert(!PC || WGW == 1, "the wave-specialised form is one integrating + one producing wavefront");
+    __shared__ NT s_norm[PC ? RING : 1];
+    __shared__ int s_hs[2], s_go[2 * WGW];
     __shared__ unsigned long long s_cnt[WGW * 3];
     __shared__ uint32_t s_rng[PC ? WGW * 64 : 1];
     const int lane = (int)(threadIdx.x & 63u);
@@ -326,20 +333,18 @@ __global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR st
 
     if (producer) {
         // per env-step: wait for the stream positions (H1), then stay one chunk ahead of integrating wavefront `cw`.
-        // Normals per chunk: RK45 6 (initial step) then 18 per attempt; RK4 12 per sub-step; Euler and the
-        // Ornstein-Uhlenbeck field 3 per sub-step
-        constexpr int n_first = SOLVER == STG_SOLVER_RK45 ? 6 : (SOLVER == STG_SOLVER_RK4 ? 12 : 3);
+        // Normals per chunk: RK45 6 (initial step) then 18 per attempt; the fixed-step solvers 12 = one RK4 sub-step
+        // with the white field, or four sub-steps of Euler / of the Ornstein-Uhlenbeck field (3 each)
+        constexpr int n_first = SOLVER == STG_SOLVER_RK45 ? 6 : 12;     // (Euler / OU: SHARED_SUBS3 sub-steps of 3)
+        static_assert(3 * SHARED_SUBS3 == 12, "chunk size of the 3-normal sub-steps");
         constexpr int n_chunk = SOLVER == STG_SOLVER_RK45 ? 18 : n_first;
-        const bool ou = a.c.inv_tau > 0.0;
         const double ghs = FIELD ? load_llgs(row).ghs : 0.0;
         for (int k = 0; k < a.K; ++k) {
             __syncthreads();                                       // H1: s_rng / s_go[k & 1] published
             const int p = (k & 1) * WGW;
             if (!any_flag<WGW>(s_go + p)) continue;
-            const bool serve = s_go[p + cw] != 0;
             const RngKey rk{a.c.seed, env_id, s_rng[cw * 64 + lane]};
-            if (SOLVER == STG_SOLVER_RK4 && ou) produce_normals<NT, FIELD, WGW>(s_norm + cw * RING, s_alive, cw, lane, rk, 3, 3, ghs, serve);
-            else produce_normals<NT, FIELD, WGW>(s_norm + cw * RING, s_alive, cw, lane, rk, n_first, n_chunk, ghs, serve);
+            produce_normals<NT, FIELD, DEPTH, BARRIER>(s_norm, s_hs, lane, rk, n_first, n_chunk, ghs);
         }
         return;
     }
@@ -369,16 +374,17 @@ __global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR st
         const RngKey rk{a.c.seed, env_id, rng};
         SolveOut so{m, 0, 0, 0, false};
         if (PC) {
-            // H1: this wavefront's stream positions and whether it integrates at all; then, if anybody in the workgroup
-            // does, H2 (chunk 0 is in LDS) and the solve, which every integrating wavefront of the workgroup walks chunk
-            // for chunk (lanes that do not integrate are inert)
-            SharedNormalsT<NT, FIELD, WGW> shared{s_norm + cw * RING, s_alive, cw, lane, 0, 0};
+            // H1: this wavefront's stream positions and whether it integrates at all; then, if it does, H2 (chunk 0 is in
+            // LDS, the handshake words are reset) and the solve (lanes that do not integrate are inert); inside the solve
+            // the two wavefronts keep in step through the handshake words, not barriers
+            SharedNormalsT<NT, FIELD, DEPTH, BARRIER> shared{s_norm, s_hs, lane, 0, 0, 1};
             const int p = (k & 1) * WGW;
             s_rng[cw * 64 + lane] = rng;
             const bool mine = __ballot(lane_solves) != 0ull;
             s_go[p + cw] = mine ? 1 : 0;
             __syncthreads();                                       // H1
             if ((WGW == 1) ? mine : any_flag<WGW>(s_go + p)) {
+                if (!BARRIER) s_hs[1] = 0;                         // (the producer is past its last read of the previous solve's value: H1)
                 __syncthreads();                                   // H2
                 so = run_solver<SOLVER, THERMAL, false, AXIS_Z, DEVPHYS>(m, J, T, row, a.c, rk, norec, shared, lane_solves);
             }

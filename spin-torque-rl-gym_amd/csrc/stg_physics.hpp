@@ -278,26 +278,36 @@ struct RngKey {
 // ---- where a solve gets its normals from ---------------------------------------------------------------------
 // InlineNormals: the integrating lane runs the stream itself (default).
 // SharedNormals: wave specialisation.  The workgroup has a second wavefront (the producer) that runs the SAME per-env
-// streams one chunk (= one RK4 sub-step / one RK45 attempt) ahead and leaves the normals in LDS; the integrating
-// wavefront only reads them.  The RNG + Box-Muller work (40 % of a thermal RK45 attempt, 65 % of a thermal RK4
-// sub-step) leaves the critical path of the longest lane; the values, their order and therefore the results are
-// identical.  One s_barrier per chunk keeps the two wavefronts in step; loop control is wave-uniform (ballot).
+// streams ahead of the integrating wavefront, one chunk (= one RK4 sub-step / one RK45 attempt) at a time, and leaves
+// the normals in an LDS ring; the integrating wavefront only reads them.  The RNG + Box-Muller work (40 % of a thermal
+// RK45 attempt, 65 % of a thermal RK4 sub-step) leaves the critical path of the longest lane; the values, their order
+// and therefore the results are identical.  Two ways of keeping the pair in step, chosen per solver by measurement:
+//  * BARRIER (RK45, Euler): one s_barrier per chunk, ring of 2; the producer fills chunk k+1 while the integrator works
+//    on chunk k and then parks at the barrier, where it costs the SIMD it shares with another workgroup's integrating
+//    wavefront nothing.
+//  * handshake words (RK4, where the producer is as busy as the integrator and a barrier per sub-step makes each
+//    wait for the other's jitter: 0.61 -> 0.56 ms per step at 65 536 envs): hs[0] = chunks the producer has
+//    published, hs[1] = chunks the integrator is through with (| PC_STOP: it stops here); ring of DEPTH = 4.  The
+//    producer fills chunk k (slot k % DEPTH) once hs[1] >= k - DEPTH + 1; the integrator reads chunk k once
+//    hs[0] > k.  Release stores / acquire loads at workgroup scope order the ring accesses around the words.  Both
+//    wavefronts belong to one workgroup, so both are resident and each one's wait ends by the other's progress;
+//    PC_STOP ends the producer's loop, and a poll budget (PC_SPIN_CAP, ~1 s) turns a protocol error into a failed
+//    solve instead of a hung GPU.  (For RK45 and Euler this form measured 5-10 % slower than the barrier.)
 struct InlineNormals {
     static constexpr bool kShared = false, kScaled = false;
     NormalStream ns;
     __device__ __forceinline__ void begin(const RngKey& rk) { ns.init(rk.seed, rk.env_id, rk.env_step, 0u); }
     __device__ __forceinline__ V3 draw(bool even) { return even ? ns.draw3_even() : ns.draw3_odd(); }
+    static constexpr bool broken = false;
+    __device__ __forceinline__ void peek() {}
     __device__ __forceinline__ bool chunk_end(bool lane_continues) { return lane_continues; }
 };
 
 constexpr int SHARED_CHUNK_MAX = 18;     // normals per chunk: RK45 attempt 18, RK4 sub-step 12, Euler 3, RK45 prologue 6
+constexpr int SHARED_SUBS3 = 4;          // sub-steps per chunk for the solvers that draw 3 normals per sub-step
+constexpr int PC_STOP = 1 << 30;
+constexpr int PC_SPIN_CAP = 1 << 22;
 
-// T = float: raw normals (fixed-step solvers, whose producer is the critical wavefront and should do no extra work);
-// T = double, SCALED: the finished thermal field c * z (RK45, whose producer has slack: the integrating wavefront
-// saves the conversions and the scaling of every RHS call).
-// A workgroup holds WGW integrating wavefronts (1 or 4) and as many producers; s_barrier is workgroup-wide, so all of
-// them run chunk for chunk in lockstep until the last integrating wavefront is through: `alive` has one flag per
-// integrating wavefront (two copies, alternating per chunk) and everybody ORs them after the rendezvous.
 template <int WGW>
 __device__ __forceinline__ bool any_flag(volatile int* f) {
     int v = f[0];
@@ -305,43 +315,80 @@ __device__ __forceinline__ bool any_flag(volatile int* f) {
     for (int j = 1; j < WGW; ++j) v |= f[j];
     return v != 0;
 }
+__device__ __forceinline__ int pc_load(const int* p) {
+    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+__device__ __forceinline__ void pc_store(int* p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
-template <typename T, bool SCALED, int WGW>
+// T = float: raw normals (fixed-step solvers, whose producer is the critical wavefront and should do no extra work);
+// T = double, SCALED: the finished thermal field c * z (RK45: the integrating wavefront saves the conversions and the
+// scaling of every RHS call).  DEPTH = chunks in the ring (a power of two; 2 with BARRIER).
+template <typename T, bool SCALED, int DEPTH, bool BARRIER>
 struct SharedNormalsT {
+    static_assert(!BARRIER || DEPTH == 2, "the barrier form runs the producer exactly one chunk ahead");
     static constexpr bool kShared = true, kScaled = SCALED;
-    const T* buf;           // this wavefront's LDS ring [2][SHARED_CHUNK_MAX][64]
-    volatile int* alive;    // LDS [2][WGW]
-    int cw, lane, it, idx;
-    __device__ __forceinline__ void begin(const RngKey&) { it = 0; idx = 0; }
+    const T* buf;           // this workgroup's LDS ring [DEPTH][SHARED_CHUNK_MAX][64]
+    int* hs;                // LDS: the handshake words / BARRIER: the integrator's "continues" flag, two alternating copies
+    int lane, it, idx, seen;   // seen: the producer's count as last read (a lane-uniform value in a VGPR)
+#ifdef STG_PROFILE_LOOP
+    int waited = 0, polls = 0;
+#endif
+    bool broken;               // the poll budget ran out (never, unless the protocol is broken): the solve reports failure
+    __device__ __forceinline__ void begin(const RngKey&) { it = 0; idx = 0; seen = 1; broken = false; }    // chunk 0 is there (H2)
     __device__ __forceinline__ V3 draw(bool) {
-        const T* b = buf + ((it & 1) * SHARED_CHUNK_MAX + idx) * 64 + lane;
+        const T* b = buf + ((it & (DEPTH - 1)) * SHARED_CHUNK_MAX + idx) * 64 + lane;
         idx += 3;
         return V3{(double)b[0], (double)b[64], (double)b[128]};
     }
-    // end of a chunk: this wavefront's (wave-uniform) wish to continue is published, then the rendezvous; returns
-    // whether ANY integrating wavefront of the workgroup continues
+    // an early look at the producer's count (relaxed: nothing waits for it here), so that chunk_end usually finds the
+    // next chunk published without an LDS round trip of its own
+    __device__ __forceinline__ void peek() {
+        if (!BARRIER) seen = __hip_atomic_load(hs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // end of a chunk: publishes that the slot is free and whether this (wave-uniform) wavefront continues; returns
+    // that, once the next chunk is in LDS.  Straight-line when the producer is ahead (the normal case).
     __device__ __forceinline__ bool chunk_end(bool lane_continues) {
-        const int p = (it & 1) * WGW;
         const bool mine = __ballot(lane_continues) != 0ull;
-        alive[p + cw] = mine ? 1 : 0;
-        __syncthreads();
-        const bool any = (WGW == 1) ? mine : any_flag<WGW>(alive + p);    // (no LDS round trip when it is our own flag)
+        if (BARRIER) {
+            ((volatile int*)hs)[it & 1] = mine ? 1 : 0;
+            __syncthreads();
+            ++it;
+            idx = 0;
+            return mine;
+        }
         ++it;
         idx = 0;
-        return any;
+        pc_store(hs + 1, it | (mine ? 0 : PC_STOP));
+        int have = __builtin_amdgcn_readfirstlane(seen);
+        if (__builtin_expect(mine && have <= it, 0)) {
+            int spins = 0;
+#ifdef STG_PROFILE_LOOP
+            ++waited;
+#endif
+#pragma unroll 1
+            do {
+                if (spins) __builtin_amdgcn_s_sleep(1);
+                have = pc_load(hs);
+#ifdef STG_PROFILE_LOOP
+                ++polls;
+#endif
+            } while (have <= it && ++spins <= PC_SPIN_CAP);
+            broken = broken || have <= it;
+        }
+        seen = have;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // the ring reads below stay below
+        return mine && !broken;
     }
 };
 
-// The producer wavefront's side for one solve of the integrating wavefront `served`: chunk 0 has n_first normals, later
-// chunks n_chunk; calls alternate between the even and odd phase of the stream across chunk boundaries, exactly as the
-// integrator's calls do.  It stays one chunk ahead while its own integrating wavefront is alive (`serve`), and keeps
-// taking part in the workgroup's rendezvous until the last one is through.
-template <typename T, bool SCALED, int WGW>
-__device__ __forceinline__ void produce_normals(T* buf, volatile int* alive, int served, int lane, const RngKey& rk,
-                                                int n_first, int n_chunk, double c, bool serve) {
+// The producer wavefront's side for one solve: chunk 0 has n_first normals, later chunks n_chunk; calls alternate
+// between the even and odd phase of the stream across chunk boundaries, exactly as the integrator's calls do.
+template <typename T, bool SCALED, int DEPTH, bool BARRIER>
+__device__ __forceinline__ void produce_normals(T* buf, int* hs, int lane, const RngKey& rk, int n_first, int n_chunk, double c) {
     NormalStream ns;
     ns.init(rk.seed, rk.env_id, rk.env_step, 0u);
-    int it = 0;
     bool even = true;
     auto fill = [&](int slot, int count) {
         T* b = buf + (slot * SHARED_CHUNK_MAX) * 64 + lane;
@@ -356,16 +403,31 @@ __device__ __forceinline__ void produce_normals(T* buf, volatile int* alive, int
             b[(j + 0) * 64] = (T)z.x; b[(j + 1) * 64] = (T)z.y; b[(j + 2) * 64] = (T)z.z;
         }
     };
-    if (serve) fill(0, n_first);
-    __syncthreads();                                   // chunk 0 ready (the integrating wavefronts wait here too)
-    for (;;) {
-        if (serve) fill((it + 1) & 1, n_chunk);        // next chunk, while the integrating wavefront works on chunk `it`
-        __syncthreads();                               // = the integrating wavefronts' chunk_end rendezvous
-        const int p = (it & 1) * WGW;
-        serve = serve && alive[p + served] != 0;
-        const bool go = any_flag<WGW>(alive + p);
-        ++it;
-        if (!go) break;
+    fill(0, n_first);
+    if (!BARRIER) pc_store(hs, 1);
+    __syncthreads();                                   // H2: chunk 0 ready (the integrating wavefront waits here too)
+    if (BARRIER) {
+        for (int k = 1;; ++k) {
+            fill(k & 1, n_chunk);                      // chunk k, while the integrating wavefront works on chunk k - 1
+            __syncthreads();                           // = the integrating wavefront's chunk_end rendezvous
+            if (((volatile int*)hs)[(k - 1) & 1] == 0) return;
+#ifdef STG_EXP_SLEEP
+            __builtin_amdgcn_s_sleep(STG_EXP_SLEEP);
+#endif
+        }
+    }
+    for (int k = 1;; ++k) {
+        // slot k % DEPTH held chunk k - DEPTH: wait until the integrator is through with it
+        int v = pc_load(hs + 1);
+#pragma unroll 1
+        for (int spins = 0; (v & (PC_STOP - 1)) < k - DEPTH + 1 && !(v & PC_STOP); ++spins) {
+            if (spins > PC_SPIN_CAP) return;
+            __builtin_amdgcn_s_sleep(1);
+            v = pc_load(hs + 1);
+        }
+        if (v & PC_STOP) return;
+        fill(k & (DEPTH - 1), n_chunk);
+        pc_store(hs, k + 1);
     }
 }
 
@@ -637,6 +699,7 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
             const V3 f2 = simple_stage<THERMAL, AXIS_Z, DEVPHYS>(y2, k, kJ2, z1, dv, on2);
             const V3 y3{__builtin_fma(half_dt, f2.x, m.x), __builtin_fma(half_dt, f2.y, m.y), __builtin_fma(half_dt, f2.z, m.z)};
             const V3 f3 = simple_stage<THERMAL, AXIS_Z, DEVPHYS>(y3, k, kJ2, z2, dv, on2);
+            if (THERMAL) ns.peek();
             const V3 y4{__builtin_fma(dt, f3.x, m.x), __builtin_fma(dt, f3.y, m.y), __builtin_fma(dt, f3.z, m.z)};
             const V3 f4 = simple_stage<THERMAL, AXIS_Z, DEVPHYS>(y4, k, kJ4, z3, dv, on4);
             // m + (k1 + 2 k2 + 2 k3 + k4)/6 with k = dt*f                  simple_solver.py:290-295
@@ -650,9 +713,15 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
         if (RECORD) rec.put(i + 1, last ? T : mul_x((double)(i + 1), dt), m, 0.0);
     };
     if (NSRC::kShared) {
+        // a chunk of the shared stream is 12 normals: one RK4 sub-step with the white field, or SHARED_SUBS3 sub-steps
+        // of the forms that take three per sub-step (Euler, the Ornstein-Uhlenbeck field) -- the rendezvous with the
+        // producer costs about as much as one Euler sub-step, so it is paid once per four
+        constexpr int SUBS = (METHOD == 1 || ou) ? SHARED_SUBS3 : 1;
         for (int i = 0;; ++i) {
             if (i < n) substep(i, std::integral_constant<int, 2>{});
-            if (!ns.chunk_end(i + 1 < n)) break;
+            if (SUBS == 1 || (i & (SUBS - 1)) == SUBS - 1) {
+                if (!ns.chunk_end(i + 1 < n)) break;
+            }
         }
     } else {
         // a counted, lane-divergent loop over the first n-1 sub-steps, then the last one with the stage gates (n >= 10)
@@ -663,7 +732,7 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
     if (THERMAL && ou_sel) run(std::true_type{}); else run(std::false_type{});
     const bool rejected_shared = NSRC::kShared && rejected_in;
     o.resets = rejected_shared ? 0 : resets;
-    if (fail || rejected_shared) return o;
+    if (fail || rejected_shared || ns.broken) return o;
     o.m = m;
     o.ok = true;
     return o;
@@ -722,6 +791,10 @@ __device__ __forceinline__ double rms3(const V3& a) { return sqrt(dot(a, a)) / 1
 // experiment builds only (-DSTG_PROFILE_LOOP): cycles spent in the segments of the RK45 attempt, summed over the attempts
 // of wavefront 0 of workgroup 0, read back with stg_debug_prof()
 static __device__ long long g_stg_prof[16];   // (one copy per translation unit; stg_debug_prof reads the RK45 unit's)
+// per integrating wavefront (first STG_PROF_WAVES workgroups x 4): start/end s_memtime, start/end s_memrealtime (100 MHz),
+// HW_ID, attempts -- where each wavefront ran, for how long, and at which shader clock
+#define STG_PROF_WAVES 8192
+static __device__ long long g_stg_wave[STG_PROF_WAVES * 6];
 #define STG_TICK(k) do { const long long now_ = __builtin_readcyclecounter(); prof_[k] += now_ - last_; last_ = now_; } while (0)
 #else
 #define STG_TICK(k) do { } while (0)
@@ -807,6 +880,7 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
 #ifdef STG_PROFILE_LOOP
     long long prof_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long last_ = __builtin_readcyclecounter();
+    const long long wave_t0_ = last_, wave_r0_ = __builtin_amdgcn_s_memrealtime();
 #endif
     bool active = enabled && (t != T);       // (a disabled lane only walks the workgroup's chunk loop)
     bool wave_go = true;
@@ -816,6 +890,10 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
       // The loop is wave-uniform and its body has no lane-divergent control flow: a lane that is through (or never
       // started) walks along with its state frozen by the selects below.  (The lane-divergent form -- break per lane,
       // exec-masked body -- spent as long on its mask bookkeeping at the top of every iteration as on one RHS.)
+      // (shared source: the first two fields of the attempt are fetched before anything else, their LDS latency runs
+      // under the step-size bookkeeping)
+      V3 z2 = zero, z3 = zero;
+      if (THERMAL && NSRC::kShared) { z2 = draw(true); z3 = draw(false); }
       const bool fail_now = active && (h_abs < min_step || attempts >= max_attempts);     // rk.py:132-133 (+ budget)
       ok = ok && !fail_now;
       active = active && !fail_now;
@@ -831,8 +909,7 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
         const bool on_end = add_x(t, h) <= T;
         const V3 k1 = f;
         // normal-stream phases alternate per call (k2: even, k3: odd, ...); each field is fetched one call ahead
-        const V3 z2 = draw(true);
-        const V3 z3 = draw(false);
+        if (THERMAL && !NSRC::kShared) { z2 = draw(true); z3 = draw(false); }
         const V3 k2 = fun(V3{y.x + (k1.x * A21) * h, y.y + (k1.y * A21) * h, y.z + (k1.z * A21) * h}, z2, true);
         STG_TICK(1);
         const V3 z4 = draw(true);
@@ -848,6 +925,7 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
                              y.y + (k1.y * A51 + k2.y * A52 + k3.y * A53 + k4.y * A54) * h,
                              y.z + (k1.z * A51 + k2.z * A52 + k3.z * A53 + k4.z * A54) * h}, z5, true);
         STG_TICK(4);
+        if (THERMAL) ns.peek();
         const V3 z7 = draw(false);
         const V3 k6 = fun(V3{y.x + (k1.x * A61 + k2.x * A62 + k3.x * A63 + k4.x * A64 + k5.x * A65) * h,
                              y.y + (k1.y * A61 + k2.y * A62 + k3.y * A63 + k4.y * A64 + k5.y * A65) * h,
@@ -897,12 +975,25 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         for (int j = 0; j < 10; ++j) g_stg_prof[j] = prof_[j];
         g_stg_prof[10] = attempts;
+        if constexpr (NSRC::kShared) { g_stg_prof[11] = ns.waited; g_stg_prof[12] = ns.polls; }
+    }
+    {
+        const int wid_ = blockIdx.x * ((int)blockDim.x / 64) + (int)threadIdx.x / 64;
+        long long att_max_ = attempts;
+        for (int o_ = 32; o_ > 0; o_ >>= 1) { const long long v_ = __shfl_xor(att_max_, o_); att_max_ = v_ > att_max_ ? v_ : att_max_; }
+        if ((threadIdx.x & 63) == 0 && wid_ < STG_PROF_WAVES) {
+            long long* r_ = g_stg_wave + 6 * wid_;
+            r_[0] = wave_t0_; r_[1] = __builtin_readcyclecounter(); r_[2] = wave_r0_; r_[3] = __builtin_amdgcn_s_memrealtime();
+            r_[4] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11))      // HW_REG_HW_ID, 32 bits
+                    | ((long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32);    // HW_REG_XCC_ID
+            r_[5] = att_max_;
+        }
     }
 #endif
     if (!RECORD) { emit(); --npts; }
     o.n = npts - 1;
     o.work = attempts;
-    o.ok = ok;
+    o.ok = ok && !ns.broken;
     if (!ok) o.m = m0;
     return o;
 }

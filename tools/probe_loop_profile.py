@@ -30,5 +30,6 @@ att = out[10]
 names = ["loop top/guard", "stage 2", "stage 3", "stage 4", "stage 5", "stage 6", "y_new + f_new", "error norm + controller"]
 tot = sum(out[k] for k in range(8))
 print(f"n={n} thermal={thermal} random={random_pulses}: step {ms:.3f} ms; wavefront 0 of workgroup 0: attempts {att}, total {tot} ticks = {tot/att:.0f} per attempt; {ms*1e6/max(tot,1):.3f} ns per tick if that wavefront spans the launch")
+print(f"  integrator found the next chunk missing {out[11]} times ({out[12]} polls)")
 for k, nm in enumerate(names):
     print(f"  {nm:26s} {out[k]/att:8.1f} ticks/attempt")
