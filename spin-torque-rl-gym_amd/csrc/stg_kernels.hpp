@@ -286,9 +286,9 @@ __device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool
 // wavefront gets a second wavefront that runs the normal streams of the same envs one chunk ahead into LDS
 // (stg_physics.hpp: SharedNormalsT).  Same values in the same order, so results are identical.  It is launched with
 // WGW = 1 (128-thread workgroups): the dispatcher was observed to put the two wavefronts on different SIMDs and to give
-// every SIMD one integrating and one producing wavefront at 65 536 envs (tools/probes/wave_placement.hip).  The code
-// supports WGW = 4 (producer 4+w serves integrating wavefront 3-w, all eight in lockstep) but that form measured no
-// better for RK45 and 8 % worse for RK4, so it is not instantiated.
+// every SIMD one integrating and one producing wavefront at 65 536 envs (tools/probes/wave_placement.hip).  (A 4 + 4
+// form -- producer 4+w serving integrating wavefront 3-w, all eight in lockstep -- was built and measured: no better
+// for RK45, 8 % worse for RK4; it is gone.)
 template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, bool DEVPHYS, typename AT, bool PC, int WGW>
 #ifndef STG_STEP_ATTR
 #define STG_STEP_ATTR
@@ -298,7 +298,10 @@ __global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR st
     // instantiation, and the same as NumPy's
 #pragma clang fp contract(off)
     static_assert(!PC || THERMAL, "wave specialisation only exists for the thermal kernels");
-    __shared__ double s_tab[MULTI ? STG_MAX_CLASSES * C_COUNT : 1];
+    // class table (MULTI): dynamic LDS sized by the launch -- n_classes rows, or one row per lane with per-env
+    // parameters -- so that a three-class batch does not reserve the 23.5 KB of STG_MAX_CLASSES rows (which kept the
+    // fourth wave-specialised workgroup off a CU)
+    extern __shared__ double s_tab[];
     // normals rings of the wave-specialised kernels (one per integrating wavefront): RK45 hands over finished fields
     // (double), the fixed-step solvers raw normals (float)
     constexpr bool FIELD = SOLVER == STG_SOLVER_RK45;
@@ -463,13 +466,19 @@ __global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR st
 // ------------------------------------------------------------------------------------------------
 constexpr int64_t STG_WG4_MIN_ENVS = 65536;       // 256 CUs x 4 SIMDs x 64 lanes
 
+// dynamic LDS of a launch: the class table of a MULTI kernel (see stg_step_kernel)
+template <bool MULTI>
+static size_t step_dyn_lds(const StepArgs& a) {
+    return MULTI ? (size_t)(a.ep.soa ? 64 : a.ncls) * C_COUNT * sizeof(double) : 0;
+}
+
 template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, bool DEVPHYS, int WGW>
 static void launch_step_w(const StepArgs& a, int act_f64, bool pc, hipStream_t st) {
     const dim3 grid((unsigned)((a.N + WGW * 64 - 1) / (WGW * 64)));
     if (act_f64)
-        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, double, false, WGW>), grid, dim3(WGW * 64), 0, st, a);
+        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, double, false, WGW>), grid, dim3(WGW * 64), step_dyn_lds<MULTI>(a), st, a);
     else
-        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, float, false, WGW>), grid, dim3(WGW * 64), 0, st, a);
+        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, float, false, WGW>), grid, dim3(WGW * 64), step_dyn_lds<MULTI>(a), st, a);
 }
 
 template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, bool DEVPHYS>
@@ -480,9 +489,9 @@ static void launch_step(const StepArgs& a, int act_f64, bool pc, hipStream_t st)
         constexpr bool PC = THERMAL && !DEVPHYS;
         const dim3 grid((unsigned)((a.N + 63) / 64));
         if (act_f64)
-            hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, double, PC, 1>), grid, dim3(128), 0, st, a);
+            hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, double, PC, 1>), grid, dim3(128), step_dyn_lds<MULTI>(a), st, a);
         else
-            hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, float, PC, 1>), grid, dim3(128), 0, st, a);
+            hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, float, PC, 1>), grid, dim3(128), step_dyn_lds<MULTI>(a), st, a);
         return;
     }
     // workgroups of 4 integrating wavefronts once there is one per CU, of 1 below that
