@@ -393,11 +393,7 @@ __device__ __forceinline__ void produce_normals(T* buf, int* hs, int lane, const
     auto fill = [&](int slot, int count) {
         T* b = buf + (slot * SHARED_CHUNK_MAX) * 64 + lane;
         for (int j = 0; j < count; j += 3) {
-#ifdef STG_EXP_NO_RNG
-            V3 z{0.25, -0.5, 0.125};
-#else
             V3 z = even ? ns.draw3_even() : ns.draw3_odd();
-#endif
             if (SCALED) z = scale3(c, z);
             even = !even;
             b[(j + 0) * 64] = (T)z.x; b[(j + 1) * 64] = (T)z.y; b[(j + 2) * 64] = (T)z.z;
@@ -411,9 +407,6 @@ __device__ __forceinline__ void produce_normals(T* buf, int* hs, int lane, const
             fill(k & 1, n_chunk);                      // chunk k, while the integrating wavefront works on chunk k - 1
             __syncthreads();                           // = the integrating wavefront's chunk_end rendezvous
             if (((volatile int*)hs)[(k - 1) & 1] == 0) return;
-#ifdef STG_EXP_SLEEP
-            __builtin_amdgcn_s_sleep(STG_EXP_SLEEP);
-#endif
         }
     }
     for (int k = 1;; ++k) {
