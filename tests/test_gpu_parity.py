@@ -938,10 +938,15 @@ def test_randomised_configurations_vs_oracle(stg, solver):
     """Randomised cross-check: device parameters drawn inside the validator's ranges (incl. tilted easy axes, demag
     factors, damping up to 0.3), log-uniform float32 pulse durations from the 1 ps minimum upwards (the roundings behind
     H4/H5 and the RK45 pulse gate), currents from 0 to the limit, thermal off and on, two steps each -- HIP vs oracle."""
-    rng = np.random.default_rng({"rk4": 101, "euler": 202, "rk45": 303}[solver])
+    # STG_RANDOM_SWEEP=<offset>[,<cases>] widens the sweep by hand (other parameter draws, more cases); default: fixed.
+    # (Thermal cases with a very small volume can exceed the tolerance there: the device's fp32 log/sin/cos differ from
+    # libm's by an ulp, and a strong field over hundreds of Euler sub-steps amplifies that to ~1e-7 -- the
+    # wave-specialised and one-wavefront kernels stay bit-identical; tools/diag_random_case.py shows both.)
+    sweep = [int(x) for x in os.environ.get("STG_RANDOM_SWEEP", "0,6").split(",")]
+    rng = np.random.default_rng({"rk4": 101, "euler": 202, "rk45": 303}[solver] + 1000 * sweep[0])
     n = 96
     worst = 0.0
-    for case in range(6):
+    for case in range(sweep[1] if len(sweep) > 1 else 6):
         thermal = bool(case & 1)
         vol = float(10 ** rng.uniform(-11.5, -10) if solver != "rk45" else 10 ** rng.uniform(-5.7, -4.5))
         axis = np.array([0.0, 0.0, 1.0]) if case < 2 else np.array([rng.normal(0, 0.3), rng.normal(0, 0.3), 1.0])
