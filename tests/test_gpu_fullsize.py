@@ -1,0 +1,415 @@
+"""Parity at the BENCHMARKED sizes, for the BENCHMARKED kernel instantiations (`pytest -m gpu`).
+
+bench.py checks nothing, so every configuration it times is run here at its own launch size and compared with the
+oracle on contiguous 64-env slices spread over the batch (first / last tile, tile and XCD-group boundaries, a slice
+straddling two tiles); the oracle backend of a slice is keyed with the slice's global env index (`env_id0`), exactly as a
+multi-GPU shard is.  On top of that, the scheduling options (duration-sorted lane schedule, producer/consumer wavefront
+pairs) and the partition of the batch must not change a single bit at that size.
+
+  cfg 3 headline .. RK45, thermal on, 65 536 envs, autoreset: stg_step_kernel<2,true,false,true,false,float,true,1>, the
+                    `nwg == 1024` slot map of the wave-specialised launch (csrc/stg_kernels.hpp: stg_slot_block)
+  cfg 4 ........... 262 144 mixed STT/SOT/VCMA envs, RK4, reference RHS and torque_model='device': MULTI x WGW = 4
+  cfg 2 ........... RK45, T = 0 K, 4 096 envs: every env against the oracle
+  cfg 2a .......... 1 048 576 envs, one 1 ps DP5 step per pulse, step_many K = 8 against 8 x step and the oracle
+Reference semantics: envs/spin_torque_env.py:310-407 (step), :250-308 (reset).  Tolerances as in test_gpu_parity.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import sot_default_params, stt_default_params, vcma_default_params
+
+pytestmark = pytest.mark.gpu
+
+TOL_RK4 = 1e-10
+TOL_RK45 = 1e-8
+SLICE = 64
+
+
+@pytest.fixture(scope="module")
+def stg():
+    import spin_torque_gym_amd as s
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    return s
+
+
+def _inputs(n, seed, jmax=2e6, tlo=1e-10, thi=1e-9, steps=2):
+    """bench.py's input distribution (make_actions): J ~ U[-jmax, jmax], pulse ~ U[tlo, thi] as float32; m0 uniform on the
+    sphere, targets +-z."""
+    rng = np.random.default_rng(seed)
+    v = rng.normal(0, 1, (n, 3))
+    m0 = v / np.linalg.norm(v, axis=1, keepdims=True)
+    tgt = np.where(rng.integers(0, 2, (n, 1)) == 0, 1.0, -1.0) * np.array([[0.0, 0.0, 1.0]])
+    acts = np.empty((steps, n, 2), dtype=np.float32)
+    acts[..., 0] = rng.uniform(-jmax, jmax, (steps, n))
+    acts[..., 1] = rng.uniform(tlo, thi, (steps, n))
+    return m0, tgt, acts
+
+
+def _slice_starts(n):
+    """64-env slices spread over the tiles (4096 envs) and XCD groups of the schedule: both ends, the first tile boundary
+    (a slice straddling tiles 0 and 1), odd tiles in the middle, the last complete group of 8 tiles."""
+    tile = 4096
+    cand = [0, tile - 32, tile + 7 * 64, 3 * tile + 1024, n // 2 - 64, n // 2 + tile + 192, (n // (8 * tile)) * 8 * tile - 2 * 64,
+            n - 5 * tile + 320, n - tile - 64, n - 64]
+    out = []
+    for s in cand:
+        s = int(min(max(s, 0), n - SLICE))
+        if all(abs(s - o) >= SLICE for o in out):
+            out.append(s)
+    return out
+
+
+def _run_hip(stg, n, m0, tgt, acts, cls=None, keep=None, **kw):
+    """Steps the HIP env through `acts`; returns the device tensors of every step (cloned) -- `keep` (index tensor on the
+    device) restricts what is kept to those envs (the 1M-env case)."""
+    env = stg.SpinTorqueVecEnv(n, class_index=cls, **kw)
+    env.reset(options={"initial_state": m0, "target_state": tgt})
+    sel = (lambda t: t.index_select(-1, keep)) if keep is not None else (lambda t: t)
+    rec = []
+    for a in acts:
+        o, r, te, tr, info = env.step(torch.from_numpy(a))
+        st = env.get_state()
+        d = dict(obs=sel(o.t()).clone(), reward=sel(info["reward_f64"]).clone(), term=sel(te).clone(), trunc=sel(tr).clone(),
+                 status=sel(info["status"]).clone(), energy=sel(info["energy"]).clone(), m=sel(st["m"]).clone(),
+                 step_count=sel(st["step_count"]).clone())
+        if kw.get("autoreset"):
+            d["final_obs"] = sel(info["final_obs"].t()).clone()
+        rec.append(d)
+    counters = env.backend.counters()
+    env.close()
+    return rec, counters
+
+
+def _run_oracle_slice(stg, s0, m0, tgt, acts, cls=None, **kw):
+    from helpers import OracleBackend
+    sl = slice(s0, s0 + SLICE)
+    env = stg.SpinTorqueVecEnv(SLICE, class_index=None if cls is None else cls[sl], env_id0=s0, backend=OracleBackend, **kw)
+    env.reset(options={"initial_state": m0[sl], "target_state": tgt[sl]})
+    rec = []
+    for a in acts:
+        o, r, te, tr, info = env.step(torch.from_numpy(a[sl]))
+        st = env.get_state()
+        d = dict(obs=o.t().clone(), reward=info["reward_f64"].clone(), term=te.clone(), trunc=tr.clone(),
+                 status=info["status"].clone(), energy=info["energy"].clone(), m=st["m"].clone(),
+                 step_count=st["step_count"].clone())
+        if kw.get("autoreset"):
+            d["final_obs"] = info["final_obs"].t().clone()
+        rec.append(d)
+    env.close()
+    return rec
+
+
+def _cmp_slice(hip_rec, ora_rec, cols, tol_m, tag):
+    """hip_rec: per-step dicts of device tensors over the whole batch (or the kept envs); cols: where this slice's envs
+    sit in them.  Envs that were auto-reset carry a state redrawn from fp32 device normals (1e-7 from libm's): their
+    later steps are compared loosely, everything before and including the reset step exactly as tightly as the rest."""
+    worst = 0.0
+    redrawn = np.zeros(SLICE, dtype=bool)
+    for k, (h, o) in enumerate(zip(hip_rec, ora_rec)):
+        g = lambda key: h[key][..., cols].cpu().numpy()
+        clean = ~redrawn
+        assert np.array_equal(g("status")[clean], o["status"].numpy()[clean]), (tag, k)
+        assert np.array_equal(g("term")[clean], o["term"].numpy()[clean]) and np.array_equal(g("trunc")[clean], o["trunc"].numpy()[clean]), (tag, k)
+        done = (o["term"].numpy() | o["trunc"].numpy()).astype(bool)
+        ended = done & clean if "final_obs" in h else np.zeros(SLICE, dtype=bool)
+        keep = clean & ~ended                       # envs whose state after this step is the integrated one
+        dm = np.abs(g("m") - o["m"].numpy())
+        if keep.any():
+            worst = max(worst, dm[:, keep].max())
+            assert dm[:, keep].max() <= tol_m, (tag, k, dm[:, keep].max())
+            assert np.allclose(g("obs")[:, keep], o["obs"].numpy()[:, keep], rtol=3e-7, atol=max(1e-12, 10 * tol_m)), (tag, k)
+        assert np.allclose(g("reward")[clean], o["reward"].numpy()[clean], rtol=1e-10, atol=max(1e-12, 10 * tol_m)), (tag, k)
+        assert np.allclose(g("energy")[clean], o["energy"].numpy()[clean], rtol=max(1e-12, 10 * tol_m), atol=0), (tag, k)
+        if ended.any():
+            # the terminal observation is the integrated state's; the redrawn state agrees to the fp32 normals' rounding
+            assert np.allclose(g("final_obs")[:, ended], o["final_obs"].numpy()[:, ended], rtol=3e-7, atol=max(1e-12, 10 * tol_m)), (tag, k)
+            assert dm[:, ended].max() < 2e-6, (tag, k, dm[:, ended].max())
+            assert np.array_equal(g("step_count")[ended], np.zeros(int(ended.sum()), dtype=np.int32))
+        if redrawn.any():
+            assert dm[:, redrawn & ~done].max(initial=0.0) < 1e-3, (tag, k)
+        redrawn |= ended
+    return worst
+
+
+def _assert_same_bits(a, b, tag):
+    for k, (x, y) in enumerate(zip(a, b)):
+        for key in x:
+            assert torch.equal(x[key], y[key]), (tag, k, key, int((x[key] != y[key]).sum()))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# cfg 3: the headline kernel at its own size
+# ------------------------------------------------------------------------------------------------------------------
+def test_cfg3_headline_rk45_thermal_65536_vs_oracle_slices(stg):
+    n = 65536
+    m0, tgt, acts = _inputs(n, seed=1234, steps=2)
+    kw = dict(device_params=stt_default_params(volume=9.7e-6), include_thermal_fluctuations=True, temperature=300.0,
+              solver="rk45", seed=1234, autoreset=True)
+    hip, c = _run_hip(stg, n, m0, tgt, acts, **kw)          # automatic schedule: sorted, wave-specialised, nwg == 1024
+    assert c["env_steps"] == 2 * n and c["noop_steps"] == 0
+    assert 400 < c["work_units"] / c["env_steps"] < 900      # ~<T>/max_step x 1.2 attempts: no solve was skipped
+    worst = 0.0
+    for s0 in _slice_starts(n):
+        ora = _run_oracle_slice(stg, s0, m0, tgt, acts, **kw)
+        worst = max(worst, _cmp_slice(hip, ora, slice(s0, s0 + SLICE), TOL_RK45, ("cfg3", s0)))
+    print("cfg3 headline (rk45, thermal, 65536): worst |dm| vs oracle on slices =", worst)
+    # scheduling options change nothing at this size: producer/consumer pairs off, identity lane schedule, both
+    for opt in (dict(wave_spec=False), dict(lane_sort=False), dict(wave_spec=False, lane_sort=False)):
+        other, c2 = _run_hip(stg, n, m0, tgt, acts, **kw, **opt)
+        _assert_same_bits(hip, other, ("cfg3", opt))
+        assert c2 == c
+    # determinism and partition invariance: a repeated run, and two half-size contexts with env_id0
+    again, _ = _run_hip(stg, n, m0, tgt, acts, **kw)
+    _assert_same_bits(hip, again, "cfg3 repeat")
+    h = n // 2
+    lo, _ = _run_hip(stg, h, m0[:h], tgt[:h], acts[:, :h], **kw)
+    hi, _ = _run_hip(stg, h, m0[h:], tgt[h:], acts[:, h:], env_id0=h, **kw)
+    for k in range(len(hip)):
+        for key in hip[k]:
+            assert torch.equal(hip[k][key], torch.cat([lo[k][key], hi[k][key]], dim=-1)), ("cfg3 halves", k, key)
+    norm = torch.linalg.norm(hip[-1]["m"], dim=0)
+    assert torch.all(torch.abs(norm - 1) < 1e-14)
+
+
+def test_cfg3_rk4_thermal_65536_vs_oracle_slices(stg):
+    """The env's own solver at the headline size (bench.py `also`: cfg3 rk4): RK4 producer/consumer kernel with the
+    handshake-word protocol, nwg == 1024 slot map."""
+    n = 65536
+    m0, tgt, acts = _inputs(n, seed=99, steps=2)
+    kw = dict(device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=True, temperature=300.0,
+              solver="rk4", seed=1234, autoreset=True)
+    hip, c = _run_hip(stg, n, m0, tgt, acts, **kw)
+    assert c["env_steps"] == 2 * n
+    worst = 0.0
+    for s0 in _slice_starts(n)[::2]:
+        ora = _run_oracle_slice(stg, s0, m0, tgt, acts, **kw)
+        worst = max(worst, _cmp_slice(hip, ora, slice(s0, s0 + SLICE), 1e-9, ("cfg3-rk4", s0)))
+    print("cfg3 rk4 thermal 65536: worst |dm| vs oracle on slices =", worst)
+    other, _ = _run_hip(stg, n, m0, tgt, acts, **kw, wave_spec=False, lane_sort=False)
+    _assert_same_bits(hip, other, "cfg3-rk4 options")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# cfg 4: 262 144 mixed STT/SOT/VCMA envs (MULTI x 4-wavefront workgroups)
+# ------------------------------------------------------------------------------------------------------------------
+def _cfg4_kwargs(stg, torque_model):
+    fac = stg.DeviceFactory()
+    vol = 8.75e-11
+    stt = fac.get_default_parameters("stt_mram"); stt["volume"] = vol
+    sot = fac.get_default_parameters("sot_mram"); sot.update(polarization=0.7, volume=vol)
+    vc = fac.get_default_parameters("vcma_mram"); vc.update(polarization=0.7, volume=vol)
+    return dict(device_type=["stt_mram", "sot_mram", "vcma_mram"], device_params=[stt, sot, vc],
+                include_thermal_fluctuations=False, temperature=300.0, solver="rk4", seed=1234, autoreset=True,
+                torque_model=torque_model)
+
+
+@pytest.mark.parametrize("torque_model", ["reference", "device"])
+def test_cfg4_mixed_262144_vs_oracle_slices(stg, torque_model):
+    """bench.py's cfg4 rows exactly (run_config(mixed=True)): class = env index mod 3, factory defaults of each type with
+    polarization 0.7 and the rescaled volume."""
+    n = 262144
+    cls = (np.arange(n) % 3).astype(np.uint8)
+    m0, tgt, acts = _inputs(n, seed=4321, steps=2)
+    kw = _cfg4_kwargs(stg, torque_model)
+    hip, c = _run_hip(stg, n, m0, tgt, acts, cls=cls, **kw)
+    assert c["env_steps"] == 2 * n
+    worst = 0.0
+    for s0 in _slice_starts(n):
+        ora = _run_oracle_slice(stg, s0, m0, tgt, acts, cls=cls, **kw)
+        worst = max(worst, _cmp_slice(hip, ora, slice(s0, s0 + SLICE), TOL_RK4, ("cfg4", torque_model, s0)))
+    print(f"cfg4 ({torque_model}, 262144 mixed): worst |dm| vs oracle on slices =", worst)
+    other, c2 = _run_hip(stg, n, m0, tgt, acts, cls=cls, **kw, lane_sort=False)
+    _assert_same_bits(hip, other, ("cfg4 lane_sort off", torque_model))
+    assert c2 == c
+    # a random class assignment (type-mixed wavefronts whatever the schedule does) at the same size
+    cls_r = np.random.default_rng(7).integers(0, 3, n).astype(np.uint8)
+    hip_r, _ = _run_hip(stg, n, m0, tgt, acts[:1], cls=cls_r, **kw)
+    for s0 in _slice_starts(n)[1::3]:
+        ora = _run_oracle_slice(stg, s0, m0, tgt, acts[:1], cls=cls_r, **kw)
+        _cmp_slice(hip_r, ora, slice(s0, s0 + SLICE), TOL_RK4, ("cfg4 random classes", torque_model, s0))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# cfg 2: 4096 envs, T = 0 K, RK45 -- every env
+# ------------------------------------------------------------------------------------------------------------------
+def test_cfg2_rk45_4096_every_env_vs_oracle(stg):
+    from helpers import OracleBackend
+    n = 4096
+    m0, tgt, acts = _inputs(n, seed=2, steps=2)
+    kw = dict(device_params=stt_default_params(volume=9.7e-6), include_thermal_fluctuations=False, solver="rk45", seed=1234,
+              autoreset=True)
+    hip, c = _run_hip(stg, n, m0, tgt, acts, **kw)
+    worst = 0.0
+    for s0 in range(0, n, SLICE):
+        ora = _run_oracle_slice(stg, s0, m0, tgt, acts, **kw)
+        worst = max(worst, _cmp_slice(hip, ora, slice(s0, s0 + SLICE), TOL_RK45, ("cfg2", s0)))
+    print("cfg2 rk45 4096 (every env): worst |dm| vs oracle =", worst)
+    other, _ = _run_hip(stg, n, m0, tgt, acts, **kw, lane_sort=False)
+    _assert_same_bits(hip, other, "cfg2 lane_sort off")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# cfg 2a: 1 048 576 envs, one 1 ps DP5 step per pulse, K = 8 fused
+# ------------------------------------------------------------------------------------------------------------------
+def test_cfg2a_1m_envs_step_many_k8_vs_steps_and_oracle(stg):
+    """bench.py's run_short_pulse_config: rk45, T = 0 K, default STT parameters, J = 0, every pulse 1 ps, autoreset,
+    identity schedule.  (i) step_many(K = 8) == 8 x step, bit for bit, over all 1M envs; (ii) slices against the oracle."""
+    n, K = 1048576, 8
+    m0, tgt, _ = _inputs(n, seed=8, steps=1)
+    acts = np.zeros((K, n, 2), dtype=np.float32)
+    acts[..., 1] = 1e-12
+    # a few non-trivial pulses so that the fused loop also carries J != 0, longer durations and the action clamp
+    rng = np.random.default_rng(5)
+    odd = rng.integers(0, n, 4096)
+    acts[:, odd, 0] = rng.uniform(-2e-10, 2e-10, (K, len(odd))).astype(np.float32)   # beta J ~ the precession rate: default volume, not stiff
+    acts[:, odd, 1] = rng.uniform(1e-12, 4e-12, (K, len(odd))).astype(np.float32)
+    kw = dict(solver="rk45", include_thermal_fluctuations=False, seed=1, autoreset=True, lane_sort=False)
+    starts = _slice_starts(n)
+    keep = torch.cat([torch.arange(s, s + SLICE) for s in starts]).cuda()
+
+    e1 = stg.SpinTorqueVecEnv(n, **kw)
+    e1.reset(options={"initial_state": m0, "target_state": tgt})
+    om, rm, tem, trm, im = e1.step_many(torch.from_numpy(acts), out_every=False)
+    st1 = e1.get_state()
+    c1 = e1.backend.counters()
+    e2 = stg.SpinTorqueVecEnv(n, **kw)
+    e2.reset(options={"initial_state": m0, "target_state": tgt})
+    per_step = []
+    for k in range(K):
+        o, r, te, tr, info = e2.step(torch.from_numpy(acts[k]))
+        st = e2.get_state()
+        per_step.append(dict(obs=o.t().index_select(-1, keep).clone(), reward=info["reward_f64"].index_select(-1, keep).clone(),
+                             term=te.index_select(-1, keep).clone(), trunc=tr.index_select(-1, keep).clone(),
+                             status=info["status"].index_select(-1, keep).clone(), energy=info["energy"].index_select(-1, keep).clone(),
+                             m=st["m"].index_select(-1, keep).clone(), step_count=st["step_count"].index_select(-1, keep).clone(),
+                             final_obs=info["final_obs"].t().index_select(-1, keep).clone()))
+    st2 = e2.get_state()
+    c2 = e2.backend.counters()
+    assert c1 == c2 and c1["env_steps"] == K * n
+    for key in ("m", "target", "total_energy", "step_count", "rng_step", "done"):
+        assert torch.equal(st1[key], st2[key]), key
+    assert torch.equal(om[0], o) and torch.equal(im["reward_f64"][0], info["reward_f64"])
+    assert torch.equal(tem[0], te) and torch.equal(trm[0], tr)
+    e1.close(); e2.close()
+    worst = 0.0
+    for j, s0 in enumerate(starts):
+        ora = _run_oracle_slice(stg, s0, m0, tgt, acts, **{k: v for k, v in kw.items() if k != "lane_sort"})
+        worst = max(worst, _cmp_slice(per_step, ora, slice(j * SLICE, (j + 1) * SLICE), TOL_RK45, ("cfg2a", s0)))
+    print("cfg2a (1M envs, K = 8): worst |dm| vs oracle on slices =", worst)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# cfg 3's statistical gate as SURVEY 8d.3 words it: P(switch) per (J, T_pulse) bin within binomial 3 sigma
+# ------------------------------------------------------------------------------------------------------------------
+STAT_J = (2e5, 3.5e5, 5e5, 1e6)
+STAT_T = (1e-10, 2e-10, 3e-10, 5e-10)
+STAT_N = 65536                       # samples per bin, HIP and oracle alike
+
+
+def _oracle_bins(solver, vol, m0_rows, bins, seed, per_bin=None):
+    """The oracle over len(bins) x per_bin envs with its OWN stream key (OpenMP over envs): returns per bin and env the
+    status and m_z after one env.step.  m0_rows: [len(bins) * per_bin, 3] initial states (one row per env)."""
+    per_bin = STAT_N if per_bin is None else per_bin
+    import ctypes as C
+    import oracle
+    from helpers import make_states  # noqa: F401  (same state layout)
+    n = len(bins) * per_bin
+    p = (oracle.Params * 1)(oracle.make_params(stt_default_params(volume=vol)))
+    c = oracle.make_config(solver=solver, thermal=True, seed=seed)
+    st = (oracle.EnvState * n)()
+    view = np.frombuffer(st, dtype=np.float64).reshape(n, C.sizeof(oracle.EnvState) // 8)
+    assert oracle.EnvState.m.offset == 0 and oracle.EnvState.target.offset == 24
+    view[:, 0:3] = m0_rows
+    view[:, 3:6] = [0.0, 0.0, -1.0]
+    a = np.empty((n, 2), dtype=np.float32)
+    for b, (J, T) in enumerate(bins):
+        a[b * per_bin:(b + 1) * per_bin] = (J, T)
+    outs = oracle.env_step_batch(st, a, p, None, c, env_id0=0, n_threads=0)
+    raw = np.frombuffer(outs, dtype=np.uint8).reshape(n, C.sizeof(oracle.StepOut))
+    return (raw[:, oracle.StepOut.status.offset].reshape(len(bins), per_bin).copy(),
+            view[:, 2].reshape(len(bins), per_bin).copy())
+
+
+def _binomial_gate(p_hip, p_cpu, n_hip, n_cpu, tag):
+    """|p_hip - p_cpu| within 3 sigma of the difference of two binomial estimates (pooled p)."""
+    pool = (p_hip * n_hip + p_cpu * n_cpu) / (n_hip + n_cpu)
+    sigma = np.sqrt(max(pool * (1 - pool), 1e-12) * (1.0 / n_hip + 1.0 / n_cpu))
+    z = (p_hip - p_cpu) / sigma
+    if pool * (1 - pool) * min(n_hip, n_cpu) < 5:        # (nearly) deterministic bin: at most a handful of envs may differ
+        assert abs(p_hip - p_cpu) * min(n_hip, n_cpu) <= 8, (tag, p_hip, p_cpu)
+        return 0.0
+    assert abs(z) <= 3.0, (tag, p_hip, p_cpu, z)
+    return z
+
+
+def test_cfg3_switching_statistics_grid_independent_streams(stg):
+    """SURVEY 8d.3 / BASELINE config 3: with the thermal field on, P(switch) and P(failed solve) per (J, T_pulse) bin must
+    match the CPU restatement run with its OWN random stream, within binomial 3 sigma, >= 65 536 samples per bin on both
+    sides.  The reference's Brown field carries no 1/sqrt(dt) (simple_solver.py:378-386): the regime in which
+    it decides outcomes at all is the torque-dominated small volume V = 1e-28 m^3, where it tips sub-steps between
+    "components overflow -> +z -> solve succeeds" and "norm overflows -> zero row -> solve fails" (H3); a 4 x 4 grid there
+    spans P(fail) from ~1 % to ~98 %.  One launch of 16 x 65 536 = 1 048 576 envs (bin = block of envs), the env's own
+    RK4 solver.  Seeds are fixed, so the test is deterministic; the 3 sigma bound is per bin."""
+    bins = [(J, T) for J in STAT_J for T in STAT_T]
+    n = len(bins) * STAT_N
+    m0 = np.array([0.05, 0.0, 1.0]); m0 /= np.linalg.norm(m0)
+    par = stt_default_params(volume=1e-28)
+    env = stg.SpinTorqueVecEnv(n, device_params=par, include_thermal_fluctuations=True, solver="rk4", seed=11)
+    env.reset(options={"initial_state": m0, "target_state": np.array([0.0, 0.0, -1.0])})
+    a = np.empty((n, 2), dtype=np.float32)
+    for b, (J, T) in enumerate(bins):
+        a[b * STAT_N:(b + 1) * STAT_N] = (J, T)
+    _, _, te, tr, info = env.step(torch.from_numpy(a))
+    st_h = info["status"].cpu().numpy().reshape(len(bins), STAT_N)
+    mz_h = env.get_state()["m"][2].cpu().numpy().reshape(len(bins), STAT_N)
+    env.close()
+    st_c, mz_c = _oracle_bins("rk4", 1e-28, np.tile(m0, (n, 1)), bins, seed=22)
+    zs, stochastic = [], 0
+    for b, (J, T) in enumerate(bins):
+        f_h, f_c = float((st_h[b] == 1).mean()), float((st_c[b] == 1).mean())
+        s_h, s_c = float((mz_h[b] < 0).mean()), float((mz_c[b] < 0).mean())
+        print(f"bin J={J:g} T={T:g}: P(fail) HIP {f_h:.4f} CPU {f_c:.4f}   P(switch) HIP {s_h:.4f} CPU {s_c:.4f}")
+        zs.append(_binomial_gate(f_h, f_c, STAT_N, STAT_N, ("fail", J, T)))
+        zs.append(_binomial_gate(s_h, s_c, STAT_N, STAT_N, ("switch", J, T)))
+        stochastic += int(0.01 < f_c < 0.99)
+    assert stochastic >= 12                                  # the grid really is in the stochastic regime
+    zs = np.array([z for z in zs if z != 0.0])
+    assert np.sqrt(np.mean(zs ** 2)) < 1.5, zs               # and the z scores look like unit normals, not like a bias
+
+
+def test_cfg3_switching_statistics_well_conditioned_volume(stg):
+    """The same gate at the well-conditioned volume (8.75e-11 m^3: clean +z -> -z switching, SURVEY headline 3).  The Brown
+    field is ~1e-9 of H_k there, so an env's outcome is decided by (m0, J, T); with m0 drawn independently on both sides
+    (uniform on the cap m_z > 0.5) P(switch) per bin is a genuine binomial comparison.  RK4 and the RK45 headline solver."""
+    bins = [(2e6, 6e-11), (2e6, 1e-10), (1e6, 1e-10), (1e6, 1.5e-10), (5e5, 2.5e-10), (1e6, 6e-10)]
+    n = len(bins) * STAT_N
+
+    def cap(seed):
+        rng = np.random.default_rng(seed)
+        z = rng.uniform(0.5, 1.0, n); ph = rng.uniform(0, 2 * np.pi, n); r = np.sqrt(1 - z * z)
+        return np.stack([r * np.cos(ph), r * np.sin(ph), z], axis=1)
+    a = np.empty((n, 2), dtype=np.float32)
+    for b, (J, T) in enumerate(bins):
+        a[b * STAT_N:(b + 1) * STAT_N] = (J, T)
+    for solver, vol in (("rk4", 8.75e-11), ("rk45", 9.7e-6)):
+        env = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(volume=vol), include_thermal_fluctuations=True,
+                                   solver=solver, seed=5)
+        env.reset(options={"initial_state": cap(1), "target_state": np.array([0.0, 0.0, -1.0])})
+        _, _, te, tr, info = env.step(torch.from_numpy(a))
+        st_h = info["status"].cpu().numpy().reshape(len(bins), STAT_N)
+        mz_h = env.get_state()["m"][2].cpu().numpy().reshape(len(bins), STAT_N)
+        env.close()
+        n_cpu = 16384 if solver == "rk45" else STAT_N           # (>= 16 384 own-stream oracle samples per bin)
+        rows = cap(2)
+        rows = np.concatenate([rows[b * STAT_N:b * STAT_N + n_cpu] for b in range(len(bins))])
+        st_c, mz_c = _oracle_bins(solver, vol, rows, bins, seed=6, per_bin=n_cpu)
+        assert (st_h == 0).all() and (st_c == 0).all()          # P(failed solve) = 0 on both sides
+        mixed = 0
+        for b, (J, T) in enumerate(bins):
+            s_h, s_c = float((mz_h[b] < 0).mean()), float((mz_c[b] < 0).mean())
+            print(f"{solver} V={vol:g} J={J:g} T={T:g}: P(switch) HIP {s_h:.4f} CPU {s_c:.4f}")
+            _binomial_gate(s_h, s_c, STAT_N, n_cpu, (solver, "switch", J, T))
+            mixed += int(0.02 < s_c < 0.98)
+        assert mixed >= 4, (solver, mixed)
+
