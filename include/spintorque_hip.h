@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STG_ABI_VERSION 1
+#define STG_ABI_VERSION 2
 
 typedef struct stg_ctx stg_ctx;
 
@@ -219,10 +219,11 @@ int stg_solve(stg_ctx* ctx, const double* m0, const double* J, const double* T, 
               double* m_final, int32_t* n_points, uint8_t* success, void* stream);
 
 /* as stg_solve, additionally recording the trajectory: the first traj_cap rows of t [traj_cap][N],
- * m [traj_cap][3][N] (normalised rows, llgs_solver.py:152-153), energy [traj_cap][N] (llgs_solver.py:239-262;
- * RK45 only, may be NULL).  Row 0 is t0. */
+ * m [traj_cap][3][N] (normalised rows, llgs_solver.py:152-153), energy [traj_cap][N] (llgs_solver.py:239-262) and
+ * torques [traj_cap][N] = |tau_stt| + |tau_fl| at each accepted point (llgs_solver.py:159-172); energy and torques are
+ * the LLGSSolver result dict's by-products: RK45 only, either may be NULL.  Row 0 is t0. */
 int stg_solve_traj(stg_ctx* ctx, const double* m0, const double* J, const double* T, uint32_t env_step,
-                   int32_t traj_cap, double* t, double* m, double* energy,
+                   int32_t traj_cap, double* t, double* m, double* energy, double* torques,
                    double* m_final, int32_t* n_points, uint8_t* success, void* stream);
 
 /* ---- device-class formulas (opt-in torque model) ------------------------------------------- */

@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(64) stg_solve_kernel(const SolveArgs a) {
     const int64_t N = a.N;
     const V3 m0{a.m0[i], a.m0[N + i], a.m0[2 * N + i]};
     const RngKey rk{a.c.seed, (uint64_t)(a.env_id0 + i), a.env_step};
-    const Recorder rec{a.traj_t, a.traj_m, a.traj_e, N, i, a.traj_cap};
+    const Recorder rec{a.traj_t, a.traj_m, a.traj_e, a.traj_tq, N, i, a.traj_cap};
     InlineNormals ns;
     const SolveOut so = run_solver<SOLVER, THERMAL, RECORD, false, false>(m0, a.J[i], a.T[i], row, a.c, rk, rec, ns, true);
     a.m_final[i] = so.m.x; a.m_final[N + i] = so.m.y; a.m_final[2 * N + i] = so.m.z;
@@ -377,9 +377,18 @@ int stg_set_params_per_env(stg_ctx* ctx, const double* soa_params, const uint8_t
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t N = (size_t)ctx->N;
     if (!ctx->env_soa) {
-        HIP_TRY(hipMalloc(&ctx->env_soa, sizeof(double) * STG_NPARAM * N));
-        HIP_TRY(hipMalloc(&ctx->env_type, 2 * N));
-        ctx->env_valid = ctx->env_type + N;
+        // both buffers or neither: a context is never left with one of them set
+        double* soa = nullptr;
+        uint8_t* bytes = nullptr;
+        HIP_TRY(hipMalloc(&soa, sizeof(double) * STG_NPARAM * N));
+        const hipError_t e2 = hipMalloc(&bytes, 2 * N);
+        if (e2 != hipSuccess) {
+            (void)hipFree(soa);
+            return fail(STG_E_NOMEM, std::string("hipMalloc(env_type): ") + hipGetErrorString(e2));
+        }
+        ctx->env_soa = soa;
+        ctx->env_type = bytes;
+        ctx->env_valid = bytes + N;
     }
     HIP_TRY(hipMemcpy(ctx->env_soa, soa_params, sizeof(double) * STG_NPARAM * N, hipMemcpyDeviceToDevice));
     HIP_TRY(hipMemcpy(ctx->env_type, dev_type, N, hipMemcpyDeviceToDevice));
@@ -388,10 +397,13 @@ int stg_set_params_per_env(stg_ctx* ctx, const double* soa_params, const uint8_t
     int32_t h_flag[2] = {0, 0};
     int32_t* d_flag = nullptr;
     HIP_TRY(hipMalloc(&d_flag, 8));
-    HIP_TRY(hipMemset(d_flag, 0, 8));
-    hipLaunchKernelGGL(stg_env_axis_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, ctx->env_soa, (int64_t)N, d_flag);
-    HIP_TRY(hipMemcpy(h_flag, d_flag, 8, hipMemcpyDeviceToHost));
-    (void)hipFree(d_flag);
+    hipError_t ef = hipMemset(d_flag, 0, 8);
+    if (ef == hipSuccess) {
+        hipLaunchKernelGGL(stg_env_axis_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, ctx->env_soa, (int64_t)N, d_flag);
+        ef = hipMemcpy(h_flag, d_flag, 8, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_flag);                                  // on every path
+    if (ef != hipSuccess) return fail(STG_E_HIP, std::string("axis flags: ") + hipGetErrorString(ef));
     ctx->axis_z = h_flag[0] == 0;
     ctx->axis_z_llgs = h_flag[1] == 0;
     ctx->ncls = 0; ctx->cls = nullptr;
@@ -501,7 +513,7 @@ static void dispatch_solve(const SolveArgs& a, bool thermal, bool multi, hipStre
 }  // extern "C++"
 
 static int solve_common(stg_ctx* ctx, const double* m0, const double* J, const double* T, uint32_t env_step,
-                        int32_t traj_cap, double* tt, double* tm, double* te, double* m_final, int32_t* n_points,
+                        int32_t traj_cap, double* tt, double* tm, double* te, double* ttq, double* m_final, int32_t* n_points,
                         uint8_t* success, void* stream, bool record) {
     if (!ctx) return fail(STG_E_INVALID, "ctx is NULL");
     if (!ctx->have_params) return fail(STG_E_STATE, "stg_set_params must precede stg_solve");
@@ -513,7 +525,7 @@ static int solve_common(stg_ctx* ctx, const double* m0, const double* J, const d
     a.c = cfg_view(ctx->cfg); a.N = ctx->N; a.env_id0 = ctx->env_id0;
     a.ctab = ctx->ctab; a.cls = ctx->cls; a.ncls = ctx->ncls;
     a.m0 = m0; a.J = J; a.T = T; a.env_step = env_step; a.m_final = m_final; a.n_points = n_points; a.success = success;
-    a.traj_cap = traj_cap; a.traj_t = tt; a.traj_m = tm; a.traj_e = te;
+    a.traj_cap = traj_cap; a.traj_t = tt; a.traj_m = tm; a.traj_e = te; a.traj_tq = ttq;
     const bool multi = ctx->ncls > 1;
     hipStream_t st = (hipStream_t)stream;
     const bool th_simple = ctx->cfg.thermal && ctx->cfg.temperature > 0, th_llgs = ctx->cfg.thermal != 0;
@@ -534,13 +546,13 @@ static int solve_common(stg_ctx* ctx, const double* m0, const double* J, const d
 
 int stg_solve(stg_ctx* ctx, const double* m0, const double* J, const double* T, uint32_t env_step, double* m_final,
               int32_t* n_points, uint8_t* success, void* stream) {
-    return solve_common(ctx, m0, J, T, env_step, 0, nullptr, nullptr, nullptr, m_final, n_points, success, stream, false);
+    return solve_common(ctx, m0, J, T, env_step, 0, nullptr, nullptr, nullptr, nullptr, m_final, n_points, success, stream, false);
 }
 
 int stg_solve_traj(stg_ctx* ctx, const double* m0, const double* J, const double* T, uint32_t env_step, int32_t traj_cap,
-                   double* t, double* m, double* energy, double* m_final, int32_t* n_points, uint8_t* success,
+                   double* t, double* m, double* energy, double* torques, double* m_final, int32_t* n_points, uint8_t* success,
                    void* stream) {
-    return solve_common(ctx, m0, J, T, env_step, traj_cap, t, m, energy, m_final, n_points, success, stream, true);
+    return solve_common(ctx, m0, J, T, env_step, traj_cap, t, m, energy, torques, m_final, n_points, success, stream, true);
 }
 
 int stg_get_state(stg_ctx* ctx, double* m, double* target, double* total_energy, int32_t* step_count, uint32_t* rng_step,

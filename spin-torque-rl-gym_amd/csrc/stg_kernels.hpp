@@ -73,7 +73,7 @@ struct SolveArgs {
     int32_t* n_points;
     uint8_t* success;
     int32_t traj_cap;
-    double *traj_t, *traj_m, *traj_e;
+    double *traj_t, *traj_m, *traj_e, *traj_tq;
 };
 
 // ------------------------------------------------------------------------------------------------

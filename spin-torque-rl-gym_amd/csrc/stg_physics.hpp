@@ -590,9 +590,10 @@ struct Recorder {
     double* t;       // [cap][N]
     double* m;       // [cap][3][N]
     double* e;       // [cap][N] or nullptr
+    double* tq;      // [cap][N] or nullptr: |tau_stt| + |tau_fl| per accepted point (llgs_solver.py:159-172)
     int64_t N, i;
     int32_t cap;
-    __device__ __forceinline__ void put(int32_t row, double tt, const V3& mm, double ee) const {
+    __device__ __forceinline__ void put(int32_t row, double tt, const V3& mm, double ee, double tqv = 0.0) const {
         if (row < cap) {
             if (t) t[(int64_t)row * N + i] = tt;
             if (m) {
@@ -600,6 +601,7 @@ struct Recorder {
                 b[0] = mm.x; b[N] = mm.y; b[2 * N] = mm.z;
             }
             if (e) e[(int64_t)row * N + i] = ee;
+            if (tq) tq[(int64_t)row * N + i] = tqv;
         }
     }
 };
@@ -777,6 +779,16 @@ __device__ __forceinline__ double llgs_energy(const V3& m, const LlgsEnergyK& k)
     return -k.kuv * (ct * ct) + k.edemag * (k.nfac.x * (m.x * m.x) + k.nfac.y * (m.y * m.y) + k.nfac.z * (m.z * m.z));
 }
 
+// A8: |tau_stt| + |tau_fl| of LLGSSolver._compute_spin_torques at a (renormalised) trajectory point, p_hat = z
+// (llgs_solver.py:159-172,213-237): tau_stt = beta J m x (m x z), tau_fl = beta' J (m x z); zero when |J| < 1e-12.
+__device__ __forceinline__ double llgs_torque_norms(const V3& m, double bJ, double bpJ) {
+#pragma clang fp contract(off)
+    const V3 mxp{m.y, -m.x, 0.0};                           // m x z
+    const V3 mm = cross(m, mxp);
+    const V3 a{bJ * mm.x, bJ * mm.y, bJ * mm.z}, b{bpJ * mxp.x, bpJ * mxp.y, bpJ * mxp.z};
+    return sqrt((a.x * a.x + a.y * a.y) + a.z * a.z) + sqrt((b.x * b.x + b.y * b.y) + b.z * b.z);
+}
+
 __device__ __forceinline__ double rms3(const V3& a) { return sqrt(dot(a, a)) / 1.7320508075688772; }   // common.py:63-65
 
 // A7 (+A8 when RECORD): scipy solve_ivp(RK45) as LLGSSolver.solve drives it.
@@ -837,7 +849,8 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
     auto emit = [&]() {
         const double inv = rsqrt_fast(dot(y, y));
         o.m = V3{y.x * inv, y.y * inv, y.z * inv};
-        if (RECORD) rec.put(npts, t, o.m, rec.e ? llgs_energy(o.m, ek) : 0.0);
+        // (the recorded time points never pass T, so current_func(t) = J at every one of them)
+        if (RECORD) rec.put(npts, t, o.m, rec.e ? llgs_energy(o.m, ek) : 0.0, rec.tq ? llgs_torque_norms(o.m, bJ, bpJ) : 0.0);
         ++npts;
     };
     if (RECORD) emit(); else ++npts;

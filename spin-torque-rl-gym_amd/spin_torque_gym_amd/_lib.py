@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("STG_HIP_LIBRARY") or os.path.join(_HERE, "libspintorq
 
 STG_MAX_TARGETS = 8
 STG_MAX_CLASSES = 64
+ABI_VERSION = 2          # STG_ABI_VERSION of include/spintorque_hip.h this binding was written against
 STG_NPARAM = 30          # double-valued fields of stg_device_params, in declaration order
 SOLVERS = {"rk4": 0, "euler": 1, "rk45": 2}
 DEV_TYPES = {"stt_mram": 0, "sot_mram": 1, "vcma_mram": 2}
@@ -66,7 +67,7 @@ SYMBOLS = {
     "stg_device_terms": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "stg_get_counters": (C.c_int, [_VP, C.POINTER(C.c_uint64), C.c_int32]),
     "stg_solve": (C.c_int, [_VP, _VP, _VP, _VP, C.c_uint32, _VP, _VP, _VP, _VP]),
-    "stg_solve_traj": (C.c_int, [_VP, _VP, _VP, _VP, C.c_uint32, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "stg_solve_traj": (C.c_int, [_VP, _VP, _VP, _VP, C.c_uint32, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "stg_thermal_strength": (C.c_int, [_VP, C.c_int32, C.POINTER(C.c_double)]),
     "stg_thermal_normals": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_int32, _VP, _VP]),
     "stg_array_create": (C.c_int, [C.POINTER(_VP), C.c_int, C.c_int64, C.c_int64, C.POINTER(StgArrayConfig),
@@ -94,8 +95,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.stg_abi_version() != 1:
-        raise ImportError(f"ABI version mismatch: library reports {lib.stg_abi_version()}, binding expects 1")
+    if lib.stg_abi_version() != ABI_VERSION:
+        raise ImportError(f"ABI version mismatch: library reports {lib.stg_abi_version()}, binding expects {ABI_VERSION}")
     _lib = lib
     return lib
 

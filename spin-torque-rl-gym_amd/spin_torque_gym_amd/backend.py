@@ -183,8 +183,9 @@ class HipBackend:
 
     def step(self, actions, autoreset=False):
         """actions: [2,N] float32 or float64 tensor (row 0 current density, row 1 duration).  One kernel launch; the
-        RL-facing outputs land in `self.packed`.  autoreset: envs whose episode ended on the previous step are reset on
-        the device before this one."""
+        RL-facing outputs land in `self.packed`.  autoreset (same-step): an env whose episode ends ON THIS step reports
+        this step's reward / terminated / truncated, is reset on the device inside the same launch, and its `obs` row
+        already holds the new episode's first observation; the terminal observation goes to `self.final_obs`."""
         a = torch.as_tensor(actions)
         f64 = a.dtype == torch.float64
         a = self._dev(a, torch.float64 if f64 else torch.float32, (2, self.n))
@@ -258,11 +259,13 @@ class HipBackend:
         if traj_cap > 0:
             t = torch.zeros((traj_cap, n), dtype=torch.float64, device=dev)
             m = torch.zeros((traj_cap, 3, n), dtype=torch.float64, device=dev)
+            # energy and torques are LLGSSolver's by-products (llgs_solver.py:154-172), recorded together
             e = torch.zeros((traj_cap, n), dtype=torch.float64, device=dev) if want_energy else None
+            tq = torch.zeros((traj_cap, n), dtype=torch.float64, device=dev) if want_energy else None
             _lib.check(self.lib.stg_solve_traj(self._ctx, _ptr(m0), _ptr(J), _ptr(T), int(env_step), int(traj_cap),
-                                               _ptr(t), _ptr(m), _ptr(e), _ptr(mf), _ptr(npts), _ptr(succ),
+                                               _ptr(t), _ptr(m), _ptr(e), _ptr(tq), _ptr(mf), _ptr(npts), _ptr(succ),
                                                self._stream()))
-            out.update(t=t, m=m, energy=e)
+            out.update(t=t, m=m, energy=e, torques=tq)
         else:
             _lib.check(self.lib.stg_solve(self._ctx, _ptr(m0), _ptr(J), _ptr(T), int(env_step), _ptr(mf),
                                           _ptr(npts), _ptr(succ), self._stream()))

@@ -10,6 +10,7 @@ Nothing here computes physics: action clamping, integration, energy, observation
 happen in libspintorque_hip.so.  The host side keeps what is inherently host-side in the reference too:
 the seeded PCG64 generator of reset() (gymnasium.utils.seeding), the episode history list and rendering.
 """
+import time
 import warnings
 from typing import Any, Dict, List, Optional, Sequence, Union
 
@@ -66,6 +67,36 @@ def _np_random(seed=None):
     """gymnasium.utils.seeding.np_random: Generator(PCG64(SeedSequence(seed)))."""
     ss = np.random.SeedSequence(seed)
     return np.random.Generator(np.random.PCG64(ss)), ss.entropy
+
+
+class _TimerTable:
+    """Host-side timer table behind get_performance_stats() (the reference's PerformanceProfiler.get_stats shape,
+    utils/performance.py:391-474: `<op>_avg_time/_total_time/_count/_min_time/_max_time` plus named counters).  Times are
+    host wall-clock around the call: for the vector env that is the enqueue cost of an asynchronous launch, for the N = 1
+    facade (which reads the state back every step) the whole step."""
+
+    def __init__(self):
+        self._t: Dict[str, List[float]] = {}
+        self.counters: Dict[str, int] = {}
+
+    def add(self, name: str, seconds: float) -> None:
+        r = self._t.setdefault(name, [0, 0.0, float("inf"), 0.0])
+        r[0] += 1
+        r[1] += seconds
+        r[2] = min(r[2], seconds)
+        r[3] = max(r[3], seconds)
+
+    def get_stats(self) -> Dict[str, Any]:
+        out: Dict[str, Any] = {}
+        for name, (cnt, tot, lo, hi) in self._t.items():
+            out.update({f"{name}_avg_time": tot / cnt, f"{name}_total_time": tot, f"{name}_count": cnt,
+                        f"{name}_min_time": lo, f"{name}_max_time": hi})
+        out.update(self.counters)
+        return out
+
+    def reset(self) -> None:
+        self._t.clear()
+        self.counters.clear()
 
 
 def _default_env_side_params(device_type: str) -> Dict[str, Any]:
@@ -126,21 +157,28 @@ class SpinTorqueVecEnv:
         self.autoreset = bool(autoreset)
         # `backend` is a test seam: a class/callable with HipBackend's constructor signature (tests inject the CPU
         # oracle for the gloo runs and as the comparator); the product default is the HIP library, nothing else.
-        factory_fn = HipBackend if backend is None else backend
-        self.backend = factory_fn(self.num_envs, self.cfg, device_index, env_id0)
-        if per_env_params:
-            # device-to-device variation: every env gets its own record (one device class as the base); keys are the
-            # reference's device_params keys, values arrays of length num_envs ([num_envs, 3] for vectors)
-            if len(self.devices) != 1:
-                raise ValueError("per_env_params needs exactly one base device class")
-            from .devices import per_env_param_block
-            self.backend.set_params_per_env(*per_env_param_block(flatten_params(self.devices[0]), self.num_envs,
-                                                                  per_env_params))
-        else:
-            self.backend.set_params([flatten_params(d) for d in self.devices], class_index)
+        self._backend_factory = HipBackend if backend is None else backend
+        self._device_index, self.env_id0 = int(device_index), int(env_id0)
+        self._class_index, self._per_env_params = class_index, per_env_params
+        if per_env_params and len(self.devices) != 1:
+            raise ValueError("per_env_params needs exactly one base device class")
+        self.profiler = _TimerTable()
+        self.backend = self._make_backend()
         self.single_action_space = _box([-max_current, 0.0], [max_current, max_duration], dtype=np.float32)
         self.single_observation_space = _box(-np.inf, np.inf, shape=(12,), dtype=np.float32)
         self._needs_reset = True
+
+    def _make_backend(self):
+        """One context for (num_envs, cfg, env_id0) with this env's device parameters installed."""
+        b = self._backend_factory(self.num_envs, self.cfg, self._device_index, self.env_id0)
+        if self._per_env_params:
+            # device-to-device variation: every env gets its own record (one device class as the base); keys are the
+            # reference's device_params keys, values arrays of length num_envs ([num_envs, 3] for vectors)
+            from .devices import per_env_param_block
+            b.set_params_per_env(*per_env_param_block(flatten_params(self.devices[0]), self.num_envs, self._per_env_params))
+        else:
+            b.set_params([flatten_params(d) for d in self.devices], self._class_index)
+        return b
 
     # -- Gymnasium VectorEnv-shaped API ---------------------------------------------------------------
     def reset(self, seed: Optional[int] = None, options: Optional[Dict[str, Any]] = None):
@@ -155,7 +193,9 @@ class SpinTorqueVecEnv:
         mask = options.get("mask")
         if mask is not None:
             mask = torch.as_tensor(mask).to(torch.uint8)
+        t0 = time.perf_counter()
         obs = self.backend.reset(mask, init, tgt, dev_seed)
+        self.profiler.add("reset", time.perf_counter() - t0)
         self._needs_reset = False
         return obs.t(), {}
 
@@ -165,7 +205,9 @@ class SpinTorqueVecEnv:
         a = torch.as_tensor(actions)
         if not actions_soa:
             a = a.t()
+        t0 = time.perf_counter()
         obs, rew, rew64, term, trunc, status = self.backend.step(a, autoreset=self.autoreset)
+        self.profiler.add("step", time.perf_counter() - t0)
         info = {"status": status, "reward_f64": rew64, "energy": self.backend.energy}
         if self.autoreset:
             # same-step auto-reset: rows of `obs` whose episode just ended already hold the new episode's first
@@ -178,7 +220,9 @@ class SpinTorqueVecEnv:
         a = torch.as_tensor(actions)
         if not actions_soa:
             a = a.transpose(1, 2)
+        t0 = time.perf_counter()
         obs, rew, rew64, term, trunc, status = self.backend.step_many(a, out_every=out_every, autoreset=self.autoreset)
+        self.profiler.add("step_many", time.perf_counter() - t0)
         return obs.transpose(1, 2), rew, term.bool(), trunc.bool(), {"status": status, "reward_f64": rew64,
                                                                       "energy": self.backend.energy_many}
 
@@ -196,16 +240,38 @@ class SpinTorqueVecEnv:
         return t.t().contiguous()
 
     # -- checkpoint / resume ---------------------------------------------------------------------------
+    _HOST_KEYS = ("host_rng", "cfg_seed", "env_id0")
+
     def state_dict(self):
+        """Device state + everything the random streams hang on: the host PCG64 state (reset seeds), `cfg.seed` (the
+        Philox key of the thermal field and of device-side auto-resets) and `env_id0` (its counter offset)."""
         st = {k: v.cpu() for k, v in self.backend.get_state().items()}
         st["host_rng"] = self._rng.bit_generator.state
+        st["cfg_seed"] = int(self.cfg.seed)
+        st["env_id0"] = int(self.env_id0)
         return st
 
     def load_state_dict(self, st):
-        self.backend.set_state({k: v for k, v in st.items() if k != "host_rng"})
+        """Resumes bit-for-bit: an env built with another stream key (e.g. seed=None in a new process) or env_id0 gets
+        its context rebuilt with the checkpoint's before the state is restored."""
+        seed, id0 = int(st.get("cfg_seed", self.cfg.seed)), int(st.get("env_id0", self.env_id0))
+        if seed != int(self.cfg.seed) or id0 != self.env_id0:
+            self.backend.close()
+            self.cfg.seed, self.env_id0 = seed, id0
+            self.backend = self._make_backend()
+        self.backend.set_state({k: v for k, v in st.items() if k not in self._HOST_KEYS})
         if "host_rng" in st:
             self._rng.bit_generator.state = st["host_rng"]
         self._needs_reset = False
+
+    def get_performance_stats(self) -> Dict[str, Any]:
+        """Host timer table + on-device counters (the reference's get_performance_stats shape, spin_torque_env.py:711-718;
+        its 'optimizer' entry is the result/observation cache, which is deliberately not reproduced -- SURVEY H1/H2)."""
+        c = self.backend.counters()
+        prof = self.profiler.get_stats()
+        prof.update(env_steps=c["env_steps"], solver_work_units=c["work_units"], noop_steps=c["noop_steps"])
+        return {"profiler": prof, "optimizer": {"cache": "not reproduced (SURVEY H1/H2)", "cache_hits": 0, "cache_misses": 0},
+                "health": self.get_health_report()}
 
     def get_state(self):
         return self.backend.get_state()
@@ -255,7 +321,7 @@ class SpinTorqueEnv(_EnvBase):
         self.seed(seed)
         self._vec = SpinTorqueVecEnv(1, device_type, device_params, None, target_states, max_steps, max_current,
                                      max_duration, temperature, include_thermal_fluctuations, success_threshold,
-                                     energy_penalty_weight, solver, seed if seed is not None else 0, False, False,
+                                     energy_penalty_weight, solver, seed, False, False,
                                      device_index, 0, backend=backend)
         self.device = self._vec.devices[0]
         self.target_states = self._vec.target_states
@@ -274,6 +340,8 @@ class SpinTorqueEnv(_EnvBase):
         self.episode_history: List[Dict[str, Any]] = []
         self.last_action = np.zeros(2)
         self._solve_count = 0
+        self._solve_time = [0.0, 0.0]         # last, total (wall time of the synchronous N = 1 step)
+        self.profiler = _TimerTable()
         self.renderer = None
 
     # -- seeding (spin_torque_env.py:694-697) -------------------------------------------------------------
@@ -283,6 +351,7 @@ class SpinTorqueEnv(_EnvBase):
 
     # -- reset (spin_torque_env.py:250-308) -----------------------------------------------------------------
     def reset(self, seed: Optional[int] = None, options: Optional[Dict[str, Any]] = None):
+        t_reset = time.perf_counter()
         if seed is not None:
             self._np_random, _ = _np_random(seed)
         options = options or {}
@@ -300,6 +369,7 @@ class SpinTorqueEnv(_EnvBase):
         obs, _ = self._vec.reset(options={"initial_state": np.asarray(m0, dtype=np.float64)[None, :],
                                           "target_state": np.asarray(tgt, dtype=np.float64)[None, :]})
         self._pull_state()
+        self.profiler.add("env_reset", time.perf_counter() - t_reset)
         return obs[0].cpu().numpy().copy(), self._get_info()
 
     def _pull_state(self):
@@ -323,6 +393,7 @@ class SpinTorqueEnv(_EnvBase):
             if a.dtype not in (np.float32, np.float64):
                 a = a.astype(np.float32)
             prev_alignment = float(np.dot(self.current_magnetization, self.target_magnetization))
+            t_step = time.perf_counter()
             obs, rew, term, trunc, info_t = self._vec.step(torch.from_numpy(np.ascontiguousarray(a)).unsqueeze(0))
             obs_np = obs[0].cpu().numpy().copy()
             reward = float(info_t["reward_f64"][0])
@@ -330,6 +401,9 @@ class SpinTorqueEnv(_EnvBase):
             energy = float(info_t["energy"][0])
             self._pull_state()
             self._solve_count += 1
+            dt_step = time.perf_counter() - t_step
+            self._solve_time = [dt_step, self._solve_time[1] + dt_step]
+            self.profiler.add("env_step", dt_step)
             # the kernel's parsed action comes back through the observation; recompute it in fp64 for `info`
             J, T = _parse_action_host(a, self.max_current, self.max_duration)
             self.last_action = np.array([J, T])
@@ -398,14 +472,21 @@ class SpinTorqueEnv(_EnvBase):
 
     def get_solver_info(self):
         return {"method": self.solver_name, "solve_count": self._solve_count, "timeout_count": 0,
-                "last_solve_time": 0.0, "timeout_rate": 0.0, "avg_solve_time": 0.0, "backend": "hip/gfx950"}
+                "last_solve_time": self._solve_time[0], "timeout_rate": 0.0,
+                "avg_solve_time": self._solve_time[1] / max(self._solve_count, 1), "backend": "hip/gfx950"}
 
     def get_health_report(self):
         from .harness import health_report
         return health_report(self)
 
     def get_performance_stats(self):
-        return {"profiler": {}, "optimizer": {}, "solver": self.get_solver_info(), "health": self.get_health_report()}
+        """spin_torque_env.py:711-718: {'profiler', 'optimizer', 'solver', 'health'}.  The profiler table carries this
+        facade's synchronous step()/reset() wall times (`env_step_*`, `env_reset_*`), the vector env's launch times and
+        the device counters."""
+        st = self._vec.get_performance_stats()
+        prof = dict(st["profiler"])
+        prof.update(self.profiler.get_stats())
+        return {"profiler": prof, "optimizer": st["optimizer"], "solver": self.get_solver_info(), "health": st["health"]}
 
     def analyze_episode(self):
         if not self.episode_history:

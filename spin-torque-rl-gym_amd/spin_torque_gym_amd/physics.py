@@ -91,6 +91,8 @@ class _GpuSolverBase:
                 res["m"] = out["m"].permute(0, 2, 1).cpu().numpy()
                 if out.get("energy") is not None:
                     res["energy"] = out["energy"].cpu().numpy()
+                if out.get("torques") is not None:
+                    res["torques"] = out["torques"].cpu().numpy()
         finally:
             b.close()
         self.solve_count += n
@@ -197,27 +199,27 @@ class LLGSSolver(_GpuSolverBase):
             k = max_points
         t = r["t"][:k, 0]
         m = r["m"][:k, 0, :]
-        J = _pulse_from_callable(current_func, 0.0, float(time_span[1]))
-        torques = self._torque_norms(m, J, device_params)
-        return {"t": t, "m": m, "energy": r["energy"][:k, 0], "torques": torques, "success": bool(r["success"][0])}
-
-    def _torque_norms(self, m, J, p):
-        """|tau_stt| + |tau_fl| along the trajectory (llgs_solver.py:159-172,213-237); a by-product for plotting."""
-        if abs(J) < 1e-12:
-            return np.zeros(len(m))
-        beta = p.get("polarization", 0.7) * self.gamma / (2 * p.get("saturation_magnetization", 800e3) * p.get("volume", 1e-24))
-        mxp = np.cross(m, np.array([0.0, 0.0, 1.0]))
-        return np.linalg.norm(beta * J * np.cross(m, mxp), axis=1) + np.linalg.norm(0.1 * beta * J * mxp, axis=1)
+        # energy and |tau_stt| + |tau_fl| per accepted point are recorded by the kernel (llgs_solver.py:154-172)
+        return {"t": t, "m": m, "energy": r["energy"][:k, 0], "torques": r["torques"][:k, 0], "success": bool(r["success"][0])}
 
     def find_stable_states(self, device_params: Dict[str, Any], n_trials: int = 100, threshold: float = 1e-6,
-                           relax_time: float = 10e-9, seed: Optional[int] = None) -> np.ndarray:
-        """llgs_solver.py:264-305 as ONE batched relaxation of n_trials random initial states."""
-        rng = np.random.default_rng(seed)
-        v = rng.normal(0, 1, (n_trials, 3))
-        m0 = v / np.linalg.norm(v, axis=1, keepdims=True)
-        r = self.solve_batch(m0, np.zeros(n_trials), np.full(n_trials, relax_time), device_params, thermal_noise=False)
+                           relax_time: float = 10e-9, seed: Optional[int] = None, initial_states=None) -> np.ndarray:
+        """llgs_solver.py:264-305 as ONE batched relaxation of the n_trials random initial states (J = 0, no field, thermal
+        off, 10 ns).  The reference draws each trial's state from the GLOBAL legacy generator -- `np.random.normal(0, 1, 3)`
+        per trial (llgs_solver.py:275-276) -- so does this method when `seed` is None: after `np.random.seed(s)` both give
+        the same initial states, hence (within the solver tolerance) the same de-duplicated list, in the same order.
+        `seed` draws from a private `RandomState(seed)` instead (same stream as `np.random.seed(seed)`, global state
+        untouched); `initial_states` [n,3] bypasses the draws."""
+        if initial_states is not None:
+            m0 = np.asarray(initial_states, dtype=np.float64).reshape(-1, 3)
+        else:
+            gen = np.random if seed is None else np.random.RandomState(seed)
+            m0 = np.array([gen.normal(0, 1, 3) for _ in range(n_trials)], dtype=np.float64).reshape(-1, 3)
+        m0 = m0 / np.linalg.norm(m0, axis=1, keepdims=True)
+        n = len(m0)
+        r = self.solve_batch(m0, np.zeros(n), np.full(n, relax_time), device_params, thermal_noise=False)
         states = []
-        for mf, ok in zip(r["m_final"], r["success"]):
+        for mf, ok in zip(r["m_final"], r["success"]):          # llgs_solver.py:290-300: first-come de-duplication
             if ok and all(np.linalg.norm(mf - s) >= threshold for s in states):
                 states.append(mf)
         return np.array(states) if states else np.array([[0, 0, 1]])

@@ -597,7 +597,39 @@ def G17():
     save("G17_array_dict", **out)
 
 
-ALL = dict(G17=G17, G16=G16, G15=G15, G14=G14, G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11, G12=G12, G13=G13)
+def G18():
+    """find_stable_states (physics/llgs_solver.py:264-305): seeded global np.random initial states, 10 ns J = 0 relaxations."""
+    solver = LLGSSolver()
+    out = {}
+    tags = []
+    for tag, over, n_trials, seed in (("default", {}, 6, 7), ("tilted", dict(easy_axis=np.array([0.3, 0.0, 1.0])), 4, 11)):
+        params = stt_params(**over)
+        # the initial states the method will draw (llgs_solver.py:275-276), replayed from the same seed
+        np.random.seed(seed)
+        m_init = np.array([np.random.normal(0, 1, 3) for _ in range(n_trials)])
+        m_init = m_init / np.linalg.norm(m_init, axis=1, keepdims=True)
+        # every trial's relaxed state, through the same call the method makes (:281-288)
+        finals = []
+        for k in range(n_trials):
+            t0 = time.time()
+            r = guarded(300, solver.solve, m_init[k].copy(), (0, 10e-9), params, lambda t: 0.0, lambda t: np.zeros(3),
+                        thermal_noise=False)
+            finals.append(r["m"][-1].copy())
+            print(f"    G18 {tag} trial {k}: {len(r['t'])} points in {time.time() - t0:.1f}s, success={r['success']}")
+        # and the method itself
+        np.random.seed(seed)
+        states = guarded(3000, solver.find_stable_states, params, n_trials=n_trials)
+        print(f"    G18 {tag}: {len(states)} stable states\n{states}")
+        out[f"{tag}_seed"] = np.array(seed)
+        out[f"{tag}_m_init"] = m_init
+        out[f"{tag}_m_final"] = np.array(finals)
+        out[f"{tag}_stable_states"] = np.asarray(states, dtype=float)
+        tags.append(tag)
+    out["tags"] = np.array(tags)
+    save("G18_stable_states", **out)
+
+
+ALL = dict(G18=G18, G17=G17, G16=G16, G15=G15, G14=G14, G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11, G12=G12, G13=G13)
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

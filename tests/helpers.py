@@ -82,9 +82,16 @@ class OracleBackend:
         self.energy = torch.zeros(n, dtype=torch.float64)
         self.status = torch.zeros(n, dtype=torch.uint8)
         self.final_obs = torch.zeros((12, n), dtype=torch.float32)
+        self._counters = {"env_steps": 0, "work_units": 0, "noop_steps": 0}
 
     def close(self):
         pass
+
+    def counters(self, reset=False):
+        c = dict(self._counters)
+        if reset:
+            self._counters = {"env_steps": 0, "work_units": 0, "noop_steps": 0}
+        return c
 
     def set_params(self, table, cls=None):
         self.params = oracle_params(table)
@@ -149,6 +156,9 @@ class OracleBackend:
             term[i] = o.terminated
             trunc[i] = o.truncated
             status[i] = o.status
+            self._counters["env_steps"] += 1
+            self._counters["work_units"] += int(o.n_sub)
+            self._counters["noop_steps"] += int(o.status == 1)
             self.done[i] = 1 if (o.terminated or o.truncated) else 0
             if autoreset and self.done[i]:
                 # same-step auto-reset (csrc/spintorque_hip.hip): terminal obs -> final_obs, redraw, obs of the new episode
@@ -222,6 +232,7 @@ class OracleBackend:
         tt = np.zeros((max(traj_cap, 1), n))
         tm = np.zeros((max(traj_cap, 1), 3, n))
         te = np.zeros((max(traj_cap, 1), n))
+        tq = np.zeros((max(traj_cap, 1), n))
         for i in range(n):
             p = self._p(i)
             if self.cfg.solver == "rk45":
@@ -229,7 +240,7 @@ class OracleBackend:
                 mf[:, i] = r["m_final"] if r["success"] else m0[:, i]
                 npts[i] = r["n_points"] - 1
                 k = min(len(r["t"]), traj_cap)
-                tt[:k, i], tm[:k, :, i], te[:k, i] = r["t"][:k], r["m"][:k], r["energy"][:k]
+                tt[:k, i], tm[:k, :, i], te[:k, i], tq[:k, i] = r["t"][:k], r["m"][:k], r["energy"][:k], r["torques"][:k]
             else:
                 r = oracle.simple_solve(m0[:, i], T[i], p, self.ocfg, J[i], self.env_id0 + i, env_step, want_traj=traj_cap > 0)
                 mf[:, i] = r["m_final"]
@@ -244,7 +255,8 @@ class OracleBackend:
             succ[i] = r["success"]
         out = dict(m_final=torch.from_numpy(mf), n_points=torch.from_numpy(npts), success=torch.from_numpy(succ))
         if traj_cap > 0:
-            out.update(t=torch.from_numpy(tt), m=torch.from_numpy(tm), energy=torch.from_numpy(te) if want_energy else None)
+            out.update(t=torch.from_numpy(tt), m=torch.from_numpy(tm), energy=torch.from_numpy(te) if want_energy else None,
+                       torques=torch.from_numpy(tq) if want_energy else None)
         return out
 
 

@@ -22,7 +22,7 @@ def test_header_symbols_are_bound_and_exported():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared in the header but not exported"
-    assert lib.stg_abi_version() == 1
+    assert lib.stg_abi_version() == _lib.ABI_VERSION
 
 
 def test_struct_layouts_match_the_header():

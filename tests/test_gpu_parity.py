@@ -424,8 +424,29 @@ def test_solver_facades_on_gpu(stg, golden):
     c = g4["cases"][1]
     r = ls.solve(c[:3], (0, c[3]), params, lambda t: 0.0, None, thermal_noise=False)
     assert r["success"] and len(r["t"]) == len(g4["t_1"]) and np.abs(r["m"] - g4["m_1"]).max() <= TOL_RK45
+    assert np.array_equal(r["torques"], g4["torques_1"])                             # J = 0: zeros
+    # A8: |tau_stt| + |tau_fl| per accepted point, recorded on the device, against the reference's (G5, all cases)
+    g5 = golden("G5_llgs_rk45_stt")
+    for k, c5 in enumerate(g5["cases"]):
+        r5 = ls.solve(c5[:3], (0, c5[3]), stt_default_params(volume={0: 9.7e-6, 1: 2e-6}[int(c5[5])]), lambda t: c5[4], None,
+                      thermal_noise=False)
+        tq = g5[f"torques_{k}"]
+        assert len(r5["t"]) == len(tq) and np.abs(r5["torques"] - tq).max() <= 1e-8 * np.abs(tq).max(), k
+        assert np.abs(r5["energy"] - g5[f"energy_{k}"]).max() <= 1e-8 * np.abs(g5[f"energy_{k}"]).max()
     st = ls.find_stable_states(params, n_trials=64, relax_time=2e-9, threshold=0.5, seed=0)
     assert 1 <= len(st) <= 2 and np.all(np.abs(np.abs(st[:, 2]) - 1.0) < 1e-2)      # relaxes to +-z
+    # (f3) find_stable_states against the recorded reference runs (G18): the seeded global-np.random initial states, the
+    # 10 ns relaxations (solve_batch on the recorded states) and the de-duplicated list
+    from test_oracle_golden import G18_PARAMS
+    g18 = golden("G18_stable_states")
+    for tag in (str(t) for t in g18["tags"]):
+        p18 = stt_default_params(**G18_PARAMS[tag])
+        n18 = len(g18[f"{tag}_m_init"])
+        rb = ls.solve_batch(g18[f"{tag}_m_init"], np.zeros(n18), np.full(n18, 10e-9), p18)
+        assert rb["success"].all() and np.abs(rb["m_final"] - g18[f"{tag}_m_final"]).max() <= 1e-8
+        np.random.seed(int(g18[f"{tag}_seed"]))
+        st = ls.find_stable_states(p18, n_trials=n18)
+        assert st.shape == g18[f"{tag}_stable_states"].shape and np.abs(st - g18[f"{tag}_stable_states"]).max() <= 1e-8
 
 
 def test_float64_actions_match_reference_semantics(stg):

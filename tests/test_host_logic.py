@@ -175,6 +175,18 @@ def test_solver_facades_vs_golden(stg, golden):
     assert set(r) == {"t", "m", "energy", "torques", "success"} and r["success"]
     assert len(r["t"]) == len(g4["t_0"]) and np.abs(r["m"] - g4["m_0"]).max() <= 1e-9
     assert np.abs(r["energy"] - g4["energy_0"]).max() <= 1e-9 * np.abs(g4["energy_0"]).max()
+    assert np.array_equal(r["torques"], np.zeros(len(r["t"]))) and np.array_equal(g4["torques_0"], r["torques"])   # J = 0
+    g5 = golden("G5_llgs_rk45_stt")
+    c5 = g5["cases"][4]                                            # volume 9.7e-6, J = 5e5: |tau_stt| + |tau_fl| per point (A8)
+    r5 = ls.solve(c5[:3], (0, c5[3]), stt_default_params(volume=9.7e-6), lambda t: c5[4], None, thermal_noise=False)
+    assert len(r5["t"]) == len(g5["t_4"]) and np.abs(r5["torques"] - g5["torques_4"]).max() <= 1e-9 * np.abs(g5["torques_4"]).max()
+    # find_stable_states (llgs_solver.py:264-305) against the recorded run (G18): same global-np.random draws
+    g18 = golden("G18_stable_states")
+    np.random.seed(int(g18["default_seed"]))
+    st = ls.find_stable_states(params, n_trials=len(g18["default_m_init"]))
+    assert st.shape == g18["default_stable_states"].shape and np.abs(st - g18["default_stable_states"]).max() <= 1e-8
+    st2 = ls.find_stable_states(params, n_trials=len(g18["default_m_init"]), seed=int(g18["default_seed"]))
+    assert np.array_equal(st, st2)
     # batched form
     rb = rs.solve_batch(g1["m0"][:4], np.zeros(4), np.full(4, 1e-10), params)
     assert rb["m_final"].shape == (4, 3) and rb["success"].all() and (rb["n_points"] == 100).all()
@@ -331,3 +343,56 @@ def test_factory_validate_parameters(stg):
     with pytest.raises(ValueError, match="Volume"):
         fac.validate_parameters("stt_mram", {"volume": 0.0})
     assert fac.validate_parameters("sot_mram", {"damping": 7.0})["damping"] == 7.0       # the reference's SOT validator is empty
+
+
+def test_unseeded_envs_get_distinct_thermal_stream_keys(stg):
+    """an unseeded SpinTorqueEnv must not key its thermal stream with a constant -- parallel workers would
+    replay the same noise step for step (the reference draws from the unseeded global np.random)."""
+    envs = [stg.SpinTorqueEnv(backend=OracleBackend) for _ in range(3)]
+    seeds = {e._vec.cfg.seed for e in envs}
+    assert len(seeds) == 3, seeds
+    same = [stg.SpinTorqueEnv(seed=5, backend=OracleBackend)._vec.cfg.seed for _ in range(2)]
+    assert same[0] == same[1] == 5
+
+
+def test_checkpoint_resumes_noise_streams_in_a_fresh_unseeded_env(stg):
+    """state_dict carries cfg.seed (Philox key of the thermal field and the device-side auto-resets) and
+    env_id0, so a new env built with seed=None continues bit for bit."""
+    n = 48
+    kw = dict(device_params=stt_default_params(volume=1e-27), include_thermal_fluctuations=True, autoreset=True, max_steps=2,
+              backend=OracleBackend)
+    rng = np.random.default_rng(0)
+    acts = [np.stack([rng.uniform(-2e6, 2e6, n), rng.uniform(1e-10, 2e-10, n)], axis=1).astype(np.float32) for _ in range(3)]
+    e1 = stg.SpinTorqueVecEnv(n, seed=None, env_id0=640, **kw)
+    e1.reset(seed=3)
+    e1.step(torch.from_numpy(acts[0]))
+    sd = e1.state_dict()
+    assert sd["cfg_seed"] == e1.cfg.seed and sd["env_id0"] == 640
+    want = [tuple(t.clone() for t in e1.step(torch.from_numpy(a))[:4]) for a in acts[1:]]
+    e2 = stg.SpinTorqueVecEnv(n, seed=None, **kw)                 # another key, another env_id0
+    assert e2.cfg.seed != e1.cfg.seed
+    e2.load_state_dict(sd)
+    assert e2.cfg.seed == e1.cfg.seed and e2.env_id0 == 640
+    got = [tuple(t.clone() for t in e2.step(torch.from_numpy(a))[:4]) for a in acts[1:]]
+    for a, b in zip(want, got):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert torch.equal(e1.get_state()["m"], e2.get_state()["m"])
+    assert e1.reset()[0].equal(e2.reset()[0])                     # host PCG64 state travelled too
+
+
+def test_performance_stats_timer_table(stg):
+    """get_performance_stats (spin_torque_env.py:711-718): profiler table in the reference's get_stats shape
+    (utils/performance.py:456-474), fed by host timers and the device counters."""
+    env = stg.SpinTorqueEnv(include_thermal_fluctuations=False, backend=OracleBackend)
+    env.reset(seed=0)
+    for _ in range(3):
+        env.step(np.array([0.0, 1e-10], dtype=np.float32))
+    st = env.get_performance_stats()
+    assert set(st) == {"profiler", "optimizer", "solver", "health"}
+    p = st["profiler"]
+    for op, cnt in (("env_step", 3), ("env_reset", 1), ("step", 3), ("reset", 1)):
+        assert p[f"{op}_count"] == cnt and p[f"{op}_min_time"] <= p[f"{op}_avg_time"] <= p[f"{op}_max_time"]
+        assert abs(p[f"{op}_total_time"] - cnt * p[f"{op}_avg_time"]) < 1e-9
+    assert p["env_steps"] == 3 and p["solver_work_units"] == 300 and p["noop_steps"] == 0
+    assert st["solver"]["solve_count"] == 3 and st["solver"]["avg_solve_time"] > 0
+    assert st["health"]["performance_metrics"]["total_steps"] == 3

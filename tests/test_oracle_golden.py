@@ -408,3 +408,29 @@ def test_g14_ornstein_uhlenbeck_field(golden, oracle_mod):
     # and it is a different field from the white one
     cw = oracle_mod.make_config(solver="rk4", thermal=True, seed=21)
     assert np.abs(oracle_mod.simple_solve(m0, T, p, cw, J, env_id=5, env_step=2)["m_final"] - m).max() > 1e-9
+
+
+G18_PARAMS = {"default": {}, "tilted": dict(easy_axis=np.array([0.3, 0.0, 1.0]))}
+
+
+def test_g18_stable_states_relaxations(golden, oracle_mod):
+    """find_stable_states' ingredients (physics/llgs_solver.py:264-305): the seeded global-np.random initial states, the
+    10 ns J = 0 relaxations and the first-come de-duplicated list, recorded from the reference."""
+    o = oracle_mod
+    g = golden("G18_stable_states")
+    c = o.make_config("rk45")
+    for tag in (str(t) for t in g["tags"]):
+        p = o.make_params(stt_default_params(**G18_PARAMS[tag]))
+        np.random.seed(int(g[f"{tag}_seed"]))
+        m_init = np.array([np.random.normal(0, 1, 3) for _ in range(len(g[f"{tag}_m_init"]))])
+        m_init /= np.linalg.norm(m_init, axis=1, keepdims=True)
+        assert np.array_equal(m_init, g[f"{tag}_m_init"])           # the legacy MT19937 stream is the reference's
+        states = []
+        for m0, ref in zip(m_init, g[f"{tag}_m_final"]):
+            r = o.llgs_solve(m0, 10e-9, p, c, 0.0, cap=1)
+            assert r["success"] and 10000 < r["n_points"] < 12000
+            assert np.abs(r["m_final"] - ref).max() <= 1e-8, (tag, np.abs(r["m_final"] - ref).max())
+            if all(np.linalg.norm(r["m_final"] - s) >= 1e-6 for s in states):
+                states.append(r["m_final"])
+        ref_states = g[f"{tag}_stable_states"]
+        assert len(states) == len(ref_states) == 2 and np.abs(np.array(states) - ref_states).max() <= 1e-8
