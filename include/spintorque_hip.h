@@ -63,6 +63,9 @@ enum {
     STG_STATUS_INACTIVE = 3    /* env was already terminated/truncated and autoreset is off: not stepped */
 };
 
+enum { STG_OUT_SOA = 0, STG_OUT_RECORDS = 1 };
+#define STG_RECORD_BYTES 56        /* 12 x f32 obs | f32 reward | u8 terminated | u8 truncated | u8 status | u8 0 */
+
 #define STG_MAX_TARGETS 8
 #define STG_MAX_CLASSES 64
 
@@ -108,7 +111,15 @@ typedef struct {
                                        x <- d x + sqrt(1 - d^2) xi, d = exp(-dt / noise_corr_time), field = strength * x
                                        for all stages of the sub-step, x = 0 at the start of every pulse.
                                        Not available with STG_SOLVER_RK45 (no fixed dt). */
-    int32_t reserved;
+    int32_t out_layout;             /* layout of a step's RL-facing outputs (obs, reward, terminated, truncated):
+                                       STG_OUT_SOA (0, default): four caller arrays, obs component-major float[12][N];
+                                       STG_OUT_RECORDS (1): ONE array of STG_RECORD_BYTES-byte records, env index major --
+                                       record i = { float obs[12]; float reward; uint8 terminated, truncated, status, 0 } --
+                                       passed as `obs` (reward/terminated/truncated arguments are ignored, may be NULL).
+                                       A shard's records are one contiguous block, so the multi-GPU exchange is a single
+                                       all-gather straight into the learner's [N_global] record array: obs is then the
+                                       [N_global, 12] strided view of it (Gym's own orientation), no transposition or
+                                       concatenation copy anywhere. */
     double noise_corr_time;         /* correlation_time of ThermalFluctuations (default 1e-12 s); used when noise_model = 1 */
 } stg_config;
 
@@ -172,21 +183,23 @@ int stg_set_params_per_env(stg_ctx* ctx, const double* soa_params, const uint8_t
 /* SpinTorqueEnv.reset (spin_torque_env.py:250-308) for the envs with mask[i] != 0 (mask NULL: all).
  * init_m / target [dev] double[3][N]: options['initial_state'] / options['target_state'] (normalised by the kernel as
  * device.validate_magnetization does); NULL: drawn on the device (normal(0,1,3) normalised; uniform choice among
- * cfg.targets) from Philox(seed, env_id, episode).  obs_out [dev] float[12][N] may be NULL. */
+ * cfg.targets) from Philox(seed, env_id, episode).  obs_out [dev] float[12][N] (cfg.out_layout = STG_OUT_RECORDS: the
+ * record array, whose obs fields are written and whose reward/flag fields are zeroed for the reset envs) may be NULL. */
 int stg_reset(stg_ctx* ctx, const uint8_t* mask, const double* init_m, const double* target,
               uint64_t seed, float* obs_out, void* stream);
 
 /* SpinTorqueEnv.step (spin_torque_env.py:310-407) for all N envs.
  * actions [dev]: [2][N] (row 0 current density A/m^2, row 1 pulse duration s), float32 (act_f64 = 0) or float64.
- * obs float[12][N]; reward float[N]; terminated/truncated uint8[N]; optional (may be NULL): reward_f64 double[N]
+ * obs float[12][N]; reward float[N]; terminated/truncated uint8[N] (cfg.out_layout = STG_OUT_RECORDS: obs is the record
+ * array uint8[N][STG_RECORD_BYTES] and the other three are ignored); optional (may be NULL): reward_f64 double[N]
  * (the reward before rounding to fp32), energy double[N] (info['energy_consumed'], spin_torque_env.py:474-480),
  * status uint8[N] (STG_STATUS_*). */
 int stg_step(stg_ctx* ctx, const void* actions, int32_t act_f64, float* obs, float* reward, double* reward_f64,
              double* energy, uint8_t* terminated, uint8_t* truncated, uint8_t* status, void* stream);
 
 /* K consecutive env steps in one launch (state stays in registers between steps).
- * actions [K][2][N]; outputs as stg_step with a leading [K] dimension; out_every = 1 writes every step's outputs,
- * 0 only the last step's (leading dimension 1).
+ * actions [K][2][N]; outputs as stg_step with a leading [K] dimension (records: [K][N][STG_RECORD_BYTES]); out_every = 1
+ * writes every step's outputs, 0 only the last step's (leading dimension 1).
  * autoreset != 0 (same-step auto-reset, the usual GPU vector-env convention): an env whose episode ends at step k
  * reports that step's reward / terminated / truncated, is then reset on the device (as stg_reset with NULL
  * init_m/target, Philox key cfg.seed) and its obs row holds the NEW episode's first observation; final_obs

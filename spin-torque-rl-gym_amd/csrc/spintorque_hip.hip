@@ -53,6 +53,7 @@ struct ResetArgs {
     const double *init_m, *target;
     uint64_t seed;
     float* obs;
+    int32_t records;          // STG_OUT_RECORDS: obs is the record array
     EnvParams ep;
 };
 
@@ -66,7 +67,8 @@ __global__ void __launch_bounds__(64) stg_reset_kernel(const ResetArgs a) {
     if (a.mask && !a.mask[i]) {
         if (a.obs) {   // unchanged env: report its current observation (last action unknown -> 0, as after reset)
             const V3 m{a.s.mx[i], a.s.my[i], a.s.mz[i]}, t{a.s.tx[i], a.s.ty[i], a.s.tz[i]};
-            write_obs(a.obs, N, i, m, t, row, a.c, a.s.step[i], a.s.etot[i], 0.0, 0.0);
+            if (a.records) write_record(a.obs, i, m, t, row, a.c, a.s.step[i], a.s.etot[i], 0.0, 0.0, 0.0f, 0u);
+            else write_obs(a.obs, N, i, m, t, row, a.c, a.s.step[i], a.s.etot[i], 0.0, 0.0);
         }
         return;
     }
@@ -87,7 +89,10 @@ __global__ void __launch_bounds__(64) stg_reset_kernel(const ResetArgs a) {
     a.s.etot[i] = 0.0;
     a.s.step[i] = 0;
     a.s.done[i] = 0;
-    if (a.obs) write_obs(a.obs, N, i, m, t, row, a.c, 0, 0.0, 0.0, 0.0);
+    if (a.obs) {
+        if (a.records) write_record(a.obs, i, m, t, row, a.c, 0, 0.0, 0.0, 0.0, 0.0f, 0u);
+        else write_obs(a.obs, N, i, m, t, row, a.c, 0, 0.0, 0.0, 0.0);
+    }
 }
 
 __global__ void stg_normals_kernel(uint64_t seed, int64_t env_id0, int64_t N, uint32_t env_step, uint32_t call0,
@@ -271,6 +276,7 @@ static int check_cfg(const stg_config* c) {
     if (c->noise_model == 1 && !(c->noise_corr_time > 0)) return fail(STG_E_INVALID, "cfg.noise_corr_time must be positive");
     if (c->solver == STG_SOLVER_RK45 && c->max_attempts < 1) return fail(STG_E_INVALID, "cfg.max_attempts must be >= 1");
     if (c->torque_model < 0 || c->torque_model > 1) return fail(STG_E_INVALID, "cfg.torque_model must be 0 or 1");
+    if (c->out_layout != STG_OUT_SOA && c->out_layout != STG_OUT_RECORDS) return fail(STG_E_INVALID, "cfg.out_layout must be STG_OUT_SOA or STG_OUT_RECORDS");
     if (c->torque_model == 1 && c->solver == STG_SOLVER_RK45)
         return fail(STG_E_INVALID, "the device-physics torque model is implemented for the fixed-step solvers (rk4, euler)");
     return STG_OK;
@@ -436,6 +442,7 @@ int stg_reset(stg_ctx* ctx, const uint8_t* mask, const double* init_m, const dou
     a.s = ctx->s; a.c = cfg_view(ctx->cfg); a.N = ctx->N; a.env_id0 = ctx->env_id0;
     a.ctab = ctx->ctab; a.cls = ctx->cls; a.ncls = ctx->ncls; a.ep = env_params_of(ctx);
     a.mask = mask; a.init_m = init_m; a.target = target; a.seed = seed; a.obs = obs_out;
+    a.records = ctx->cfg.out_layout == STG_OUT_RECORDS ? 1 : 0;
     hipLaunchKernelGGL(stg_reset_kernel, grid_for(ctx->N), dim3(64), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     ctx->have_state = true;
@@ -448,7 +455,10 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
     if (!ctx) return fail(STG_E_INVALID, "ctx is NULL");
     if (!ctx->have_params || !ctx->have_state) return fail(STG_E_STATE, "stg_set_params and stg_reset must precede stg_step");
     if (K < 1) return fail(STG_E_INVALID, "K must be >= 1");
-    if (!actions || !obs || !reward || !terminated || !truncated) return fail(STG_E_INVALID, "actions/obs/reward/terminated/truncated must not be NULL");
+    const bool records = ctx->cfg.out_layout == STG_OUT_RECORDS;
+    if (!actions || !obs) return fail(STG_E_INVALID, "actions/obs must not be NULL");
+    if (!records && (!reward || !terminated || !truncated)) return fail(STG_E_INVALID, "reward/terminated/truncated must not be NULL (cfg.out_layout = STG_OUT_SOA)");
+    if (records && ((uintptr_t)obs & 7u)) return fail(STG_E_INVALID, "the record array must be 8-byte aligned");
     HIP_TRY(hipSetDevice(ctx->device));
     StepArgs a{};
     a.s = ctx->s; a.c = cfg_view(ctx->cfg); a.N = ctx->N; a.env_id0 = ctx->env_id0;
@@ -474,6 +484,7 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
         a.perm = ctx->perm;
     }
     a.actions = actions; a.K = K; a.out_every = out_every ? 1 : 0; a.autoreset = autoreset ? 1 : 0;
+    a.records = records ? 1 : 0;
     a.obs = obs; a.final_obs = final_obs; a.reward = reward; a.reward64 = reward_f64; a.energy = energy; a.term = terminated; a.trunc = truncated; a.status = status;
     // the Simple solver only draws a thermal field when temperature > 0 (simple_solver.py:321,378)
     const bool thermal = ctx->cfg.thermal && ctx->cfg.temperature > 0;

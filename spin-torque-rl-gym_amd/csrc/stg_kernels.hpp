@@ -52,6 +52,7 @@ struct StepArgs {
     int32_t force_wg1;
     const void* actions;          // [K][2][N]
     int32_t K, out_every, autoreset;
+    int32_t records;              // STG_OUT_RECORDS: `obs` is the record array [K or 1][N][STG_RECORD_BYTES], reward/term/trunc unused
     const uint32_t* perm;         // lane -> env (duration-sorted schedule) or nullptr
     unsigned long long* counters; // [4]: env-steps, integrator sub-steps/attempts, RHS evaluations, no-op steps
     float* obs;                   // [K or 1][12][N]
@@ -188,26 +189,47 @@ __device__ __forceinline__ void device_reset_draw(uint64_t seed, uint64_t env_id
     }
 }
 
-// A12: _get_observation (vector mode), written component-major.
-__device__ __forceinline__ void write_obs(float* obs, int64_t N, int64_t i, const V3& m, const V3& tgt, const double* row,
-                                          const CfgView& c, int32_t step, double etot, double J, double T) {
+// A12: _get_observation (vector mode): the twelve fp32 values.
+__device__ __forceinline__ void make_obs(float (&o)[12], const V3& m, const V3& tgt, const double* row, const CfgView& c,
+                                         int32_t step, double etot, double J, double T) {
 #pragma clang fp contract(off)
     const V3 ref{row[C_REFX], row[C_REFY], row[C_REFZ]};
     const double r = resistance(m, (int)row[C_DEVTYPE], row[C_RP], row[C_RAP], row[C_TMR], ref, row[C_RSERIES]);
-    obs[0 * N + i] = obs_cast(m.x);
-    obs[1 * N + i] = obs_cast(m.y);
-    obs[2 * N + i] = obs_cast(m.z);
-    obs[3 * N + i] = obs_cast(tgt.x);
-    obs[4 * N + i] = obs_cast(tgt.y);
-    obs[5 * N + i] = obs_cast(tgt.z);
-    obs[6 * N + i] = obs_cast(r / row[C_RP]);
+    o[0] = obs_cast(m.x);
+    o[1] = obs_cast(m.y);
+    o[2] = obs_cast(m.z);
+    o[3] = obs_cast(tgt.x);
+    o[4] = obs_cast(tgt.y);
+    o[5] = obs_cast(tgt.z);
+    o[6] = obs_cast(r / row[C_RP]);
     // (the normalisations by run constants are multiplications by host-computed reciprocals: <= 1 ulp of fp64 away
     // from the reference's quotients, before the cast to fp32)
-    obs[7 * N + i] = obs_cast(c.temp_norm);
-    obs[8 * N + i] = obs_cast((double)(c.max_steps - step) / (double)c.max_steps);
-    obs[9 * N + i] = obs_cast(etot * 1e12);
-    obs[10 * N + i] = obs_cast(J * c.inv_max_current);
-    obs[11 * N + i] = obs_cast(T * c.inv_max_duration);
+    o[7] = obs_cast(c.temp_norm);
+    o[8] = obs_cast((double)(c.max_steps - step) / (double)c.max_steps);
+    o[9] = obs_cast(etot * 1e12);
+    o[10] = obs_cast(J * c.inv_max_current);
+    o[11] = obs_cast(T * c.inv_max_duration);
+}
+// ... written component-major (float[12][N], env index fastest)
+__device__ __forceinline__ void write_obs(float* obs, int64_t N, int64_t i, const V3& m, const V3& tgt, const double* row,
+                                          const CfgView& c, int32_t step, double etot, double J, double T) {
+    float o[12];
+    make_obs(o, m, tgt, row, c, step, etot, J, T);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) obs[k * N + i] = o[k];
+}
+// ... or as env i's record (STG_OUT_RECORDS): { f32 obs[12]; f32 reward; u8 terminated, truncated, status, 0 } = 56 B, written
+// as seven 8-byte stores (records are 8-byte aligned: 56 i on top of an allocation's base).  One contiguous block per
+// env instead of fifteen scattered elements: with the sorted lane schedule a lane's stores then fill whole sectors.
+__device__ __forceinline__ void write_record(void* base, int64_t i, const V3& m, const V3& tgt, const double* row,
+                                             const CfgView& c, int32_t step, double etot, double J, double T, float reward,
+                                             uint32_t flags) {
+    float o[12];
+    make_obs(o, m, tgt, row, c, step, etot, J, T);
+    float2* rec = (float2*)((char*)base + i * STG_RECORD_BYTES);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) rec[k] = make_float2(o[2 * k], o[2 * k + 1]);
+    rec[6] = make_float2(reward, __uint_as_float(flags));
 }
 
 constexpr int COUNTER_STRIPES = 1024;     // copies of the on-device counters (one 64-byte line each)
@@ -439,12 +461,17 @@ __global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR st
             J = 0.0; T = 0.0;                       // last_action = zeros after reset (spin_torque_env.py:283)
         }
         if (wr) {
-            write_obs(a.obs + ko * 12 * N, N, i, m, tgt, row, a.c, step, etot, J, T);
-            a.reward[ko * N + i] = (float)reward;
+            if (a.records) {
+                write_record((char*)a.obs + ko * N * STG_RECORD_BYTES, i, m, tgt, row, a.c, step, etot, J, T, (float)reward,
+                             (is_success ? 1u : 0u) | (truncated ? 0x100u : 0u) | ((uint32_t)st << 16));
+            } else {
+                write_obs(a.obs + ko * 12 * N, N, i, m, tgt, row, a.c, step, etot, J, T);
+                a.reward[ko * N + i] = (float)reward;
+                a.term[ko * N + i] = is_success ? 1 : 0;
+                a.trunc[ko * N + i] = truncated ? 1 : 0;
+            }
             if (a.reward64) a.reward64[ko * N + i] = reward;
             if (a.energy) a.energy[ko * N + i] = energy;
-            a.term[ko * N + i] = is_success ? 1 : 0;
-            a.trunc[ko * N + i] = truncated ? 1 : 0;
             if (a.status) a.status[ko * N + i] = st;
         }
     }

@@ -17,6 +17,8 @@ ABI_VERSION = 2          # STG_ABI_VERSION of include/spintorque_hip.h this bind
 STG_NPARAM = 30          # double-valued fields of stg_device_params, in declaration order
 SOLVERS = {"rk4": 0, "euler": 1, "rk45": 2}
 DEV_TYPES = {"stt_mram": 0, "sot_mram": 1, "vcma_mram": 2}
+OUT_LAYOUTS = {"soa": 0, "records": 1}
+RECORD_BYTES = 56        # STG_RECORD_BYTES
 STATUS_OK, STATUS_NOOP, STATUS_RESET, STATUS_INACTIVE = 0, 1, 2, 3
 
 
@@ -28,7 +30,7 @@ class StgConfig(C.Structure):
         ("success_threshold", C.c_double), ("energy_penalty_weight", C.c_double),
         ("targets", (C.c_double * 3) * STG_MAX_TARGETS), ("seed", C.c_uint64), ("max_attempts", C.c_int64),
         ("skip_done", C.c_int32), ("torque_model", C.c_int32), ("wave_spec", C.c_int32), ("lane_sort", C.c_int32),
-        ("noise_model", C.c_int32), ("reserved", C.c_int32), ("noise_corr_time", C.c_double),
+        ("noise_model", C.c_int32), ("out_layout", C.c_int32), ("noise_corr_time", C.c_double),
     ]
 
 

@@ -39,6 +39,8 @@ class EnvConfig:
     wave_spec: Optional[bool] = None          # producer/consumer wavefront pairs (thermal): None = automatic
     noise_model: str = "white"                # 'white' (reference solvers) | 'ou' (ThermalFluctuations, fixed-step only)
     correlation_time: float = 1e-12           # ThermalFluctuations.correlation_time, for noise_model='ou'
+    out_layout: str = "soa"                   # 'soa': obs [12,N] + reward/terminated/truncated arrays; 'records': one
+                                              # [N,56]-byte record array (what the multi-GPU gather moves, copy-free)
 
     def to_abi(self) -> "_lib.StgConfig":
         if self.solver not in _lib.SOLVERS:
@@ -69,6 +71,9 @@ class EnvConfig:
             raise ValueError("noise_model must be 'white' or 'ou'")
         c.noise_model = int(self.noise_model == "ou")
         c.noise_corr_time = float(self.correlation_time)
+        if self.out_layout not in _lib.OUT_LAYOUTS:
+            raise ValueError("out_layout must be 'soa' or 'records'")
+        c.out_layout = _lib.OUT_LAYOUTS[self.out_layout]
         return c
 
 
@@ -86,6 +91,28 @@ def unpack_step_buffer(buf: torch.Tensor, n: int):
     obs = buf[: 48 * n].view(torch.float32).view(12, n)
     reward = buf[48 * n: 52 * n].view(torch.float32)
     return obs, reward, buf[52 * n: 53 * n], buf[53 * n: 54 * n]
+
+
+RECORD_BYTES = _lib.RECORD_BYTES   # f32 obs[12] | f32 reward | u8 terminated | u8 truncated | u8 status | u8 0
+
+
+def record_views(buf: torch.Tensor):
+    """Typed views of a record array `buf` uint8[..., n, 56] (STG_OUT_RECORDS), no copies:
+    obs f32[..., n, 12] (row stride 14 floats -- Gym's [N, 12] orientation), reward f32[..., n], terminated / truncated /
+    status u8[..., n]."""
+    f = buf.view(torch.float32)                       # [..., n, 14]
+    return f[..., :12], f[..., 12], buf[..., 52], buf[..., 53], buf[..., 54]
+
+
+def alloc_step_outputs(n: int, device, layout: str):
+    """The RL-facing outputs of one step in the given layout: (container, obs [12,n] view, reward, terminated, truncated).
+    'soa': the 54 B/env packed byte buffer (component-major obs); 'records': uint8 [n,56], obs = the transposed view."""
+    if layout == "records":
+        rec = torch.zeros((n, RECORD_BYTES), dtype=torch.uint8, device=device)
+        obs, reward, term, trunc, _ = record_views(rec)
+        return rec, obs.t(), reward, term, trunc
+    buf, (obs, reward, term, trunc) = packed_step_buffer(n, device)
+    return buf, obs, reward, term, trunc
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -111,9 +138,12 @@ class HipBackend:
         self._cls = None
         n = self.n
         dev = self.device
-        # (obs, reward, terminated, truncated) live in ONE byte buffer -- 54 B/env -- so that the multi-GPU path can
-        # move a step's results with a single RCCL all-gather; the tensors below are views.
-        self.packed, (self.obs, self.reward, self.terminated, self.truncated) = packed_step_buffer(n, dev)
+        # (obs, reward, terminated, truncated) live in ONE buffer; the tensors below are views of it.  'soa': 54 B/env,
+        # component-major obs [12,N]; 'records': [N,56] bytes, env-major -- a shard is one contiguous block, so the
+        # multi-GPU path moves a step's results with a single all-gather straight into the global record array
+        #  and `obs` is a strided [12,N] view (its .t() is Gym's [N,12]).
+        self.records_layout = cfg.out_layout == "records"
+        self.packed, self.obs, self.reward, self.terminated, self.truncated = alloc_step_outputs(n, dev, cfg.out_layout)
         self.reward64 = torch.empty(n, dtype=torch.float64, device=dev)
         self.energy = torch.empty(n, dtype=torch.float64, device=dev)
         self.status = torch.empty(n, dtype=torch.uint8, device=dev)
@@ -177,20 +207,37 @@ class HipBackend:
         init_m = self._dev(init_m, torch.float64, (3, self.n))
         target = self._dev(target, torch.float64, (3, self.n))
         _lib.check(self.lib.stg_reset(self._ctx, _ptr(mask), _ptr(init_m), _ptr(target),
-                                      int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(self.obs), self._stream()))
+                                      int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                      _ptr(self.packed if self.records_layout else self.obs), self._stream()))
         self._keep = (mask, init_m, target)      # keep inputs alive until the stream has consumed them
         return self.obs
 
-    def step(self, actions, autoreset=False):
+    def step(self, actions, autoreset=False, out: Optional[torch.Tensor] = None):
         """actions: [2,N] float32 or float64 tensor (row 0 current density, row 1 duration).  One kernel launch; the
         RL-facing outputs land in `self.packed`.  autoreset (same-step): an env whose episode ends ON THIS step reports
         this step's reward / terminated / truncated, is reset on the device inside the same launch, and its `obs` row
-        already holds the new episode's first observation; the terminal observation goes to `self.final_obs`."""
+        already holds the new episode's first observation; the terminal observation goes to `self.final_obs`.
+        out ('records' layout only): another uint8 [N,56] record array to write this step's outputs into instead of
+        `self.packed` (callers that double-buffer, e.g. the pipelined multi-GPU gather); the returned views are of `out`."""
         a = torch.as_tensor(actions)
         f64 = a.dtype == torch.float64
         a = self._dev(a, torch.float64 if f64 else torch.float32, (2, self.n))
         if autoreset and self.final_obs is None:
             self.final_obs = torch.zeros((12, self.n), dtype=torch.float32, device=self.device)
+        if self.records_layout:
+            rec = self.packed if out is None else out
+            if rec.dtype != torch.uint8 or tuple(rec.shape) != (self.n, RECORD_BYTES) or not rec.is_contiguous() or rec.device != self.device:
+                raise ValueError(f"out must be a contiguous uint8 [{self.n}, {RECORD_BYTES}] tensor on {self.device}")
+            _lib.check(self.lib.stg_step_many(self._ctx, 1, _ptr(a), int(f64), 1, int(bool(autoreset)), _ptr(rec),
+                                              _ptr(self.final_obs) if autoreset else None, None, _ptr(self.reward64),
+                                              _ptr(self.energy), None, None, _ptr(self.status), self._stream()))
+            self._keep = (a,)
+            if out is None:
+                return self.obs, self.reward, self.reward64, self.terminated, self.truncated, self.status
+            obs, reward, term, trunc, _ = record_views(rec)
+            return obs.t(), reward, self.reward64, term, trunc, self.status
+        if out is not None:
+            raise ValueError("out= needs out_layout='records'")
         _lib.check(self.lib.stg_step_many(self._ctx, 1, _ptr(a), int(f64), 1, int(bool(autoreset)), _ptr(self.obs),
                                           _ptr(self.final_obs) if autoreset else None,
                                           _ptr(self.reward), _ptr(self.reward64), _ptr(self.energy),
@@ -207,17 +254,24 @@ class HipBackend:
         a = self._dev(a, torch.float64 if f64 else torch.float32, (K, 2, self.n))
         ko = K if out_every else 1
         n, dev = self.n, self.device
-        obs = torch.empty((ko, 12, n), dtype=torch.float32, device=dev)
-        reward = torch.empty((ko, n), dtype=torch.float32, device=dev)
+        if self.records_layout:
+            rec = torch.empty((ko, n, RECORD_BYTES), dtype=torch.uint8, device=dev)
+            o, reward, term, trunc, _ = record_views(rec)
+            obs, out_ptr = o.transpose(1, 2), rec             # [ko,12,n] view
+        else:
+            obs = torch.empty((ko, 12, n), dtype=torch.float32, device=dev)
+            reward = torch.empty((ko, n), dtype=torch.float32, device=dev)
+            term = torch.empty((ko, n), dtype=torch.uint8, device=dev)
+            trunc = torch.empty((ko, n), dtype=torch.uint8, device=dev)
+            out_ptr = obs
         reward64 = torch.empty((ko, n), dtype=torch.float64, device=dev)
-        term = torch.empty((ko, n), dtype=torch.uint8, device=dev)
-        trunc = torch.empty((ko, n), dtype=torch.uint8, device=dev)
         status = torch.empty((ko, n), dtype=torch.uint8, device=dev)
         self.energy_many = torch.empty((ko, n), dtype=torch.float64, device=dev)
         self.final_obs_many = torch.zeros((ko, 12, n), dtype=torch.float32, device=dev) if autoreset else None
         _lib.check(self.lib.stg_step_many(self._ctx, K, _ptr(a), int(f64), int(bool(out_every)), int(bool(autoreset)),
-                                          _ptr(obs), _ptr(self.final_obs_many), _ptr(reward), _ptr(reward64), _ptr(self.energy_many), _ptr(term),
-                                          _ptr(trunc), _ptr(status), self._stream()))
+                                          _ptr(out_ptr), _ptr(self.final_obs_many), None if self.records_layout else _ptr(reward),
+                                          _ptr(reward64), _ptr(self.energy_many), None if self.records_layout else _ptr(term),
+                                          None if self.records_layout else _ptr(trunc), _ptr(status), self._stream()))
         self._keep = (a,)
         return obs, reward, reward64, term, trunc, status
 

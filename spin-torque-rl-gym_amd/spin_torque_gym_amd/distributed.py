@@ -1,23 +1,35 @@
 """Multi-GPU: one process per GPU, contiguous shards of independent environments, one collective per step.
 
 The reference has no distributed path at all; this is a new design for the 8-GPU MI355X node.
-Environments never interact, so the data path needs no exchange: rank r owns envs [r*n_local, (r+1)*n_local) and
-steps them with its own `stg_ctx` (Philox counters use the GLOBAL env index, so results do not depend on the number
-of ranks).  The only communication is what an RL learner needs: the step's (obs, reward, terminated, truncated),
-54 B/env, packed in one byte buffer and moved by ONE all-gather (RCCL over xGMI when the backend is "nccl"; the
-CPU tests run the same code over gloo).  At 131 072 envs per GPU that is 7.1 MB per rank per step.
+Environments never interact, so the data path needs no exchange: rank r owns envs [r*n_local, (r+1)*n_local) and steps
+them with its own `stg_ctx` (Philox counters use the GLOBAL env index, so results do not depend on the number of ranks).
+The only communication is what an RL learner needs -- the step's (obs, reward, terminated, truncated) of every env.
+
+Copy-free by layout.  The step kernel writes its outputs as 56-byte env-major RECORDS (`out_layout='records'`,
+include/spintorque_hip.h: STG_OUT_RECORDS) straight into this rank's slice of a GLOBAL record array uint8[N_global, 56];
+ONE in-place all-gather (RCCL over xGMI when the backend is "nccl"; the CPU tests run the same code over gloo) fills in
+the other ranks' slices, and what the learner gets are typed strided VIEWS of that array -- obs float32 [N_global, 12]
+(Gym's orientation), reward float32 [N_global], terminated / truncated bool [N_global].  No staging copy before the
+collective, no transposition or `torch.cat` after it.  Two global arrays alternate, so the gather of step k runs on its
+own HIP stream under the kernel of step k+1 (`gather_begin` / `gather_end`), which writes the other array.
+At 131 072 envs per GPU a rank contributes 7.3 MB per step.
+
+`gather_algo`: "all_gather" (default) = `all_gather_into_tensor`, RCCL picks the algorithm; "p2p" = one grouped batch of
+7 sends + 7 receives per rank (`batch_isend_irecv`), every peer's slice over its own xGMI link at once -- the one-shot
+alternative to a ring (ring = 7 hops per link-time, direct = 1), for steps short enough that the
+collective no longer hides under the kernel.
+
 Actions go the other way: every rank slices its shard out of the global action tensor (a learner that is itself
-data-parallel over the same ranks would pass local actions and skip the gather: ``gather=False``).
-`gather_begin` / `gather_end` split the collective from the step so that it overlaps the next step's kernel on a
-separate HIP stream (a pipelined actor that acts on observations one step old, or a recorder).
+data-parallel over the same ranks passes local actions and skips the gather: ``gather=False``).
 """
+import time
 from typing import Optional
 
 import torch
 import torch.distributed as dist
 
-from .backend import PACKED_BYTES_PER_ENV, unpack_step_buffer
-from .envs import SpinTorqueVecEnv
+from .backend import RECORD_BYTES, record_views
+from .envs import SpinTorqueVecEnv, _TimerTable
 
 
 def shard_range(n_global: int, world: int, rank: int):
@@ -27,14 +39,23 @@ def shard_range(n_global: int, world: int, rank: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def global_views(records: torch.Tensor):
+    """(obs [N,12] f32, reward [N] f32, terminated [N] bool, truncated [N] bool): strided views of a record array, no copy."""
+    obs, reward, term, trunc, _ = record_views(records)
+    return obs, reward, term.view(torch.bool), trunc.view(torch.bool)
+
+
 class ShardedSpinTorqueVecEnv:
     """`num_envs` global environments sharded over the ranks of `group` (default: the world group)."""
 
     def __init__(self, num_envs: int, group: Optional[dist.ProcessGroup] = None, device_index: Optional[int] = None,
-                 class_index=None, **env_kwargs):
+                 class_index=None, gather_algo: str = "all_gather", **env_kwargs):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised (backend 'nccl' = RCCL on ROCm, or 'gloo')")
+        if gather_algo not in ("all_gather", "p2p"):
+            raise ValueError("gather_algo must be 'all_gather' or 'p2p'")
         self.group = group
+        self.gather_algo = gather_algo
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.num_envs = int(num_envs)
@@ -46,84 +67,112 @@ class ShardedSpinTorqueVecEnv:
             device_index = self.rank % max(torch.cuda.device_count(), 1)
         if class_index is not None:
             class_index = torch.as_tensor(class_index)[self.lo:self.hi]
+        env_kwargs.pop("out_layout", None)
         self.local = SpinTorqueVecEnv(self.n_local, class_index=class_index, device_index=device_index, env_id0=self.lo,
-                                      **env_kwargs)
+                                      out_layout="records", **env_kwargs)
         dev = self.local.backend.packed.device
-        nbytes = PACKED_BYTES_PER_ENV * self.n_local
-        self._gathered = torch.zeros(self.world * nbytes, dtype=torch.uint8, device=dev)
-        # pipelined gather (gather_begin / gather_end): the step's packed outputs are copied to a staging slot and the
-        # all-gather runs on its own stream while the next step's kernel runs; two slots, so a slot is reused only
-        # after the gather that read it has finished
-        self._overlap = dev.type == "cuda" and dist.get_backend(group) != "gloo"
-        self._send = [torch.zeros(nbytes, dtype=torch.uint8, device=dev) for _ in range(2)]
-        self._recv = [self._gathered, torch.zeros_like(self._gathered)]
-        self._slot = 0
+        self.device = dev
+        # two global record arrays: the kernel of step k writes this rank's slice of array k & 1 while the gather of
+        # step k-1 (array (k-1) & 1) may still be in flight
+        self._glob = [torch.zeros((self.num_envs, RECORD_BYTES), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self._slot = 0            # array the NEXT step writes
+        self._filled = None       # array holding the last step's local records, not yet gathered
         self._pending = None
+        self._gloo = dist.get_backend(group) == "gloo"
+        self._overlap = dev.type == "cuda" and not self._gloo
+        self._done = [None, None]
         if self._overlap:
             self._comm_stream = torch.cuda.Stream(device=dev)
-            self._done = [None, None]
+        self.profiler = _TimerTable()
+
+    # -- the collective ---------------------------------------------------------------------------------------------
+    def _mine(self, k: int) -> torch.Tensor:
+        return self._glob[k][self.lo:self.hi]
+
+    def _exchange(self, k: int) -> None:
+        """Fills the other ranks' slices of global array k (this rank's slice holds its records already)."""
+        g, mine = self._glob[k], self._mine(k)
+        if self._gloo:
+            # CPU tests / single-GPU rehearsal: gloo moves host memory and is not an in-place collective
+            host = torch.empty(g.shape, dtype=torch.uint8)
+            if self.gather_algo == "p2p" and self.world > 1:
+                src = mine.cpu()
+                n = self.n_local
+                ops = []
+                for peer in range(self.world):
+                    if peer != self.rank:
+                        ops.append(dist.P2POp(dist.isend, src, peer, group=self.group))
+                        ops.append(dist.P2POp(dist.irecv, host[peer * n:(peer + 1) * n], peer, group=self.group))
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+                host[self.lo:self.hi] = src
+            else:
+                dist.all_gather_into_tensor(host.view(-1), mine.cpu().reshape(-1), group=self.group)
+            g.copy_(host)
+            return
+        if self.gather_algo == "p2p" and self.world > 1:
+            n = self.n_local
+            ops = []
+            for peer in range(self.world):
+                if peer != self.rank:
+                    ops.append(dist.P2POp(dist.isend, mine, peer, group=self.group))
+                    ops.append(dist.P2POp(dist.irecv, g[peer * n:(peer + 1) * n], peer, group=self.group))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()            # (stream-ordered on NCCL/RCCL: does not block the host)
+            return
+        # in place: the send buffer is this rank's slice of the receive buffer (NCCL/RCCL's in-place all-gather form)
+        dist.all_gather_into_tensor(g.view(-1), mine.reshape(-1), group=self.group)
 
     def _gather(self, unpack: bool = True):
-        """The single collective of a step.  unpack=False returns the raw [world * 54 * n_local] byte buffer (rank-major;
-        `unpack_step_buffer` gives typed views of each rank's slice) without the concatenation copies."""
-        packed = self.local.backend.packed
-        if packed.is_cuda and dist.get_backend(self.group) == "gloo":
-            # rehearsal only (several ranks sharing one GPU): gloo moves host memory
-            host = torch.empty(self._gathered.shape, dtype=torch.uint8)
-            dist.all_gather_into_tensor(host, packed.cpu(), group=self.group)
-            self._gathered.copy_(host)
-        else:
-            dist.all_gather_into_tensor(self._gathered, packed, group=self.group)
-        if not unpack:
-            return self._gathered
-        return self._unpack_all(self._gathered)
-
-    def _unpack_all(self, buf):
-        n = self.n_local
-        parts = [unpack_step_buffer(buf[r * PACKED_BYTES_PER_ENV * n:(r + 1) * PACKED_BYTES_PER_ENV * n], n)
-                 for r in range(self.world)]
-        obs = torch.cat([p[0] for p in parts], dim=1)       # [12, N_global]
-        reward = torch.cat([p[1] for p in parts])
-        term = torch.cat([p[2] for p in parts])
-        trunc = torch.cat([p[3] for p in parts])
-        return obs.t(), reward, term.bool(), trunc.bool()
+        """Synchronous form: gathers the last step's records and returns the typed global views (unpack=False: the
+        global record array uint8 [N_global, 56] itself)."""
+        self.gather_begin()
+        return self.gather_end(unpack)
 
     def gather_begin(self):
         """Starts the all-gather of the step just enqueued and returns at once: the collective runs on a side stream
-        (RCCL over xGMI) concurrently with whatever the caller enqueues next -- normally the next step's kernel.  Pair
-        with `gather_end`.  One gather may be in flight per slot (two slots)."""
-        k = self._slot
-        self._slot ^= 1
-        packed = self.local.backend.packed
+        (RCCL over xGMI) concurrently with whatever the caller enqueues next -- normally the next step's kernel, which
+        writes the OTHER global array.  Pair with `gather_end`."""
+        if self._filled is None:
+            raise RuntimeError("gather_begin without a step (or reset) to gather")
+        k, self._filled = self._filled, None
+        t0 = time.perf_counter()
         if not self._overlap:
-            self._pending = ("sync", self._gather(unpack=False))
-            return
-        cur = torch.cuda.current_stream(packed.device)
-        if self._done[k] is not None:
-            cur.wait_event(self._done[k])                    # the gather that last read this slot has finished
-        self._send[k].copy_(packed, non_blocking=True)       # 54 B/env device-to-device, on the compute stream
-        ready = torch.cuda.Event()
-        ready.record(cur)
-        with torch.cuda.stream(self._comm_stream):
-            self._comm_stream.wait_event(ready)
-            dist.all_gather_into_tensor(self._recv[k], self._send[k], group=self.group)
-            done = torch.cuda.Event()
-            done.record(self._comm_stream)
-        self._done[k] = done
-        self._pending = ("async", k)
+            self._exchange(k)
+            self._pending = ("sync", k)
+        else:
+            cur = torch.cuda.current_stream(self.device)
+            ready = torch.cuda.Event()
+            ready.record(cur)                                    # the step kernel that wrote this rank's slice
+            with torch.cuda.stream(self._comm_stream):
+                self._comm_stream.wait_event(ready)
+                self._exchange(k)
+                done = torch.cuda.Event()
+                done.record(self._comm_stream)
+            self._done[k] = done
+            self._pending = ("async", k)
+        self.profiler.add("gather_begin", time.perf_counter() - t0)
 
     def gather_end(self, unpack: bool = True):
-        """Makes the current stream wait for the gather started last and returns its result (see `_gather`)."""
+        """Makes the current stream wait for the gather started last; returns (obs [N,12], reward [N], terminated [N],
+        truncated [N]) as views of the global record array (valid until the step after next overwrites that array), or
+        the array itself with unpack=False."""
         if self._pending is None:
             raise RuntimeError("gather_end without gather_begin")
-        kind, v = self._pending
+        kind, k = self._pending
         self._pending = None
-        if kind == "sync":
-            buf = v
-        else:
-            torch.cuda.current_stream(self._recv[v].device).wait_event(self._done[v])
-            buf = self._recv[v]
-        return self._unpack_all(buf) if unpack else buf
+        if kind == "async":
+            torch.cuda.current_stream(self.device).wait_event(self._done[k])
+        return global_views(self._glob[k]) if unpack else self._glob[k]
+
+    # -- env API ----------------------------------------------------------------------------------------------------
+    def _next_slot(self) -> int:
+        k = self._slot
+        self._slot ^= 1
+        if self._overlap and self._done[k] is not None:
+            # the gather that last filled this array must be through before the kernel overwrites our slice of it
+            torch.cuda.current_stream(self.device).wait_event(self._done[k])
+        return k
 
     def reset(self, seed: Optional[int] = None, options=None, gather: bool = True):
         options = dict(options or {})
@@ -135,18 +184,31 @@ class ShardedSpinTorqueVecEnv:
         obs, info = self.local.reset(seed=seed, options=options)
         if not gather:
             return obs, info
-        # reset() fills the packed buffer's obs region; reward/done regions keep their previous content
+        # reset() fills the env's own record array (obs fields; reward/flags zeroed): hand it to the exchange
+        k = self._next_slot()
+        self._mine(k).copy_(self.local.backend.packed)
+        self._filled = k
         return self._gather()[0], info
 
     def step(self, actions, gather: bool = True, actions_are_local: bool = False):
+        """One env.step() of this rank's shard, written into its slice of the next global record array.  gather=True
+        also runs the exchange and returns the GLOBAL (obs, reward, terminated, truncated, {}); gather=False returns the
+        local env's outputs (views of this rank's slice) -- follow with gather_begin()/gather_end() to pipeline."""
         a = torch.as_tensor(actions)
         if not actions_are_local:
             a = a[self.lo:self.hi]
-        out = self.local.step(a)
+        k = self._next_slot()
+        out = self.local.step(a, out=self._mine(k))
+        self._filled = k
         if not gather:
             return out
         obs, reward, term, trunc = self._gather()
         return obs, reward, term, trunc, {}
+
+    def get_performance_stats(self):
+        st = self.local.get_performance_stats()
+        st["profiler"].update(self.profiler.get_stats())
+        return st
 
     def close(self):
         self.local.close()

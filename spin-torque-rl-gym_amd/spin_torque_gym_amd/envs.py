@@ -126,7 +126,7 @@ class SpinTorqueVecEnv:
                  autoreset: bool = False, skip_done: bool = False, device_index: int = 0, env_id0: int = 0,
                  max_attempts: int = 200_000, lane_sort: Optional[bool] = None, wave_spec: Optional[bool] = None, torque_model: str = "reference",
                  noise_model: str = "white", correlation_time: float = 1e-12,
-                 per_env_params: Optional[Dict[str, Any]] = None,
+                 per_env_params: Optional[Dict[str, Any]] = None, out_layout: str = "soa",
                  backend=None):
         self.num_envs = int(num_envs)
         factory = DeviceFactory()
@@ -153,7 +153,8 @@ class SpinTorqueVecEnv:
                              energy_penalty_weight=energy_penalty_weight, target_states=[list(t) for t in targets],
                              seed=int(self._rng.integers(0, 2**63 - 1)) if seed is None else int(seed),
                              max_attempts=max_attempts, skip_done=skip_done, lane_sort=lane_sort, wave_spec=wave_spec,
-                             torque_model=torque_model, noise_model=noise_model, correlation_time=correlation_time)
+                             torque_model=torque_model, noise_model=noise_model, correlation_time=correlation_time,
+                             out_layout=out_layout)
         self.autoreset = bool(autoreset)
         # `backend` is a test seam: a class/callable with HipBackend's constructor signature (tests inject the CPU
         # oracle for the gloo runs and as the comparator); the product default is the HIP library, nothing else.
@@ -199,14 +200,19 @@ class SpinTorqueVecEnv:
         self._needs_reset = False
         return obs.t(), {}
 
-    def step(self, actions, actions_soa: bool = False):
+    def step(self, actions, actions_soa: bool = False, out=None):
+        """out (out_layout='records' only): a uint8 [N,56] record array that receives this step's outputs instead of the
+        env's own (double buffering; the multi-GPU env passes its slice of the global record array)."""
         if self._needs_reset:
             raise RuntimeError("Environment must be reset before calling step")
         a = torch.as_tensor(actions)
         if not actions_soa:
             a = a.t()
         t0 = time.perf_counter()
-        obs, rew, rew64, term, trunc, status = self.backend.step(a, autoreset=self.autoreset)
+        if out is None:
+            obs, rew, rew64, term, trunc, status = self.backend.step(a, autoreset=self.autoreset)
+        else:
+            obs, rew, rew64, term, trunc, status = self.backend.step(a, autoreset=self.autoreset, out=out)
         self.profiler.add("step", time.perf_counter() - t0)
         info = {"status": status, "reward_f64": rew64, "energy": self.backend.energy}
         if self.autoreset:

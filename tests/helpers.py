@@ -76,8 +76,10 @@ class OracleBackend:
         self.params = None
         self.cls = None
         n = self.n
-        from spin_torque_gym_amd.backend import packed_step_buffer
-        self.packed, (self.obs, self.reward, self.terminated, self.truncated) = packed_step_buffer(n, self.device)
+        from spin_torque_gym_amd.backend import alloc_step_outputs
+        self.records_layout = getattr(cfg, "out_layout", "soa") == "records"
+        self.packed, self.obs, self.reward, self.terminated, self.truncated = alloc_step_outputs(
+            n, self.device, getattr(cfg, "out_layout", "soa"))
         self.reward64 = torch.zeros(n, dtype=torch.float64)
         self.energy = torch.zeros(n, dtype=torch.float64)
         self.status = torch.zeros(n, dtype=torch.uint8)
@@ -173,11 +175,18 @@ class OracleBackend:
                 self.done[i] = 0
                 self._obs_of(i, obs)
 
-    def step(self, actions, autoreset=False):
+    def step(self, actions, autoreset=False, out=None):
         a = torch.as_tensor(actions).cpu().numpy()
-        self._step_once(a, autoreset, (self.obs, self.reward, self.reward64, self.energy, self.terminated, self.truncated,
-                                   self.status))
-        return self.obs, self.reward, self.reward64, self.terminated, self.truncated, self.status
+        obs, reward, term, trunc = self.obs, self.reward, self.terminated, self.truncated
+        if out is not None:                      # 'records' layout: the caller's record array (double buffering)
+            from spin_torque_gym_amd.backend import record_views
+            assert self.records_layout and tuple(out.shape) == (self.n, 56)
+            o, reward, term, trunc, st_b = record_views(out)
+            obs = o.t()
+        self._step_once(a, autoreset, (obs, reward, self.reward64, self.energy, term, trunc, self.status))
+        if self.records_layout:                  # the record's status byte
+            (out if out is not None else self.packed)[:, 54] = self.status
+        return obs, reward, self.reward64, term, trunc, self.status
 
     def step_many(self, actions, out_every=True, autoreset=False):
         a = torch.as_tensor(actions).cpu().numpy()

@@ -875,8 +875,11 @@ def test_integration_md_ctypes_stub_runs(stg):
 
 
 def test_pipelined_gather_overlaps_and_matches_sync(stg):
-    """ShardedSpinTorqueVecEnv.gather_begin/gather_end (the all-gather on its own stream under the next step's kernel)
-    against the synchronous gather, through RCCL with a world of one rank (the 8-GPU run is the driver's)."""
+    """ShardedSpinTorqueVecEnv through RCCL with a world of one rank (the 8-GPU run is the driver's): the step kernel
+    writes 56-byte records straight into this rank's slice of the global record array, the in-place all-gather runs on
+    its own stream under the next step's kernel (gather_begin/gather_end, two arrays alternating), and the learner gets
+    typed strided views -- no staging copy, no torch.cat.  Pipelined == synchronous == the plain single-GPU env, bit for
+    bit, for the all-gather and for the point-to-point exchange."""
     import socket
     import torch.distributed as dist
     from spin_torque_gym_amd.distributed import ShardedSpinTorqueVecEnv
@@ -884,25 +887,79 @@ def test_pipelined_gather_overlaps_and_matches_sync(stg):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        n, steps = 8192, 4
+        n, steps = 8192, 5
         rng = np.random.default_rng(3)
         acts = [torch.from_numpy(_uniform_actions(2e6, 1e-10, 3e-10)(rng, n, k)) for k in range(steps)]
         kw = dict(device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=True, seed=9, autoreset=True)
-        e1 = ShardedSpinTorqueVecEnv(n, **kw); e1.reset(seed=2, gather=False)
-        e2 = ShardedSpinTorqueVecEnv(n, **kw); e2.reset(seed=2, gather=False)
-        sync = [tuple(t.clone() for t in e1.step(a)[:4]) for a in acts]
-        piped = []
-        for k, a in enumerate(acts):
-            e2.step(a, gather=False)
-            if k:
-                piped.append(tuple(t.clone() for t in e2.gather_end()))     # step k-1, gathered under step k's kernel
-            e2.gather_begin()
-        piped.append(tuple(t.clone() for t in e2.gather_end()))
-        for a, b in zip(sync, piped):
-            assert all(torch.equal(x, y) for x, y in zip(a, b))
-        e1.close(); e2.close()
+        plain = stg.SpinTorqueVecEnv(n, **kw); plain.reset(seed=2)
+        want = []
+        for a in acts:
+            o, r, te, tr, _ = plain.step(a)
+            want.append((o.clone(), r.clone(), te.clone(), tr.clone()))
+        plain.close()
+        for algo in ("all_gather", "p2p"):
+            e1 = ShardedSpinTorqueVecEnv(n, gather_algo=algo, **kw); e1.reset(seed=2, gather=False)
+            e2 = ShardedSpinTorqueVecEnv(n, gather_algo=algo, **kw); e2.reset(seed=2, gather=False)
+            sync = []
+            for a in acts:
+                o, r, te, tr, _ = e1.step(a)
+                assert tuple(o.shape) == (n, 12) and tuple(o.stride()) == (14, 1) and o.dtype == torch.float32
+                assert te.dtype == torch.bool and r.dtype == torch.float32
+                glob = [g.untyped_storage().data_ptr() for g in e1._glob]
+                assert all(t.untyped_storage().data_ptr() in glob for t in (o, r, te, tr))     # views, not copies
+                sync.append((o.clone(), r.clone(), te.clone(), tr.clone()))
+            piped = []
+            for k, a in enumerate(acts):
+                e2.step(a, gather=False)
+                if k:
+                    piped.append(tuple(t.clone() for t in e2.gather_end()))     # step k-1, gathered under step k's kernel
+                e2.gather_begin()
+            piped.append(tuple(t.clone() for t in e2.gather_end()))
+            for a, b, c in zip(sync, piped, want):
+                assert all(torch.equal(x, y) for x, y in zip(a, b)), algo
+                assert all(torch.equal(x, y) for x, y in zip(a, c)), algo
+            e1.close(); e2.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("solver,thermal", [("rk4", True), ("rk45", False)])
+def test_record_output_layout_equals_soa(stg, solver, thermal):
+    """cfg.out_layout = STG_OUT_RECORDS (56-byte env-major records: obs[12] f32 | reward f32 | terminated | truncated |
+    status) against the separate component-major arrays: same bits, for reset (incl. a mask), step with auto-reset,
+    fused steps, a caller-provided record array, sorted and identity lane schedules, ragged sizes."""
+    from spin_torque_gym_amd.backend import record_views
+    vol = 9.7e-6 if solver == "rk45" else 8.75e-11
+    for n in (1000, 70001):
+        rng = np.random.default_rng(n)
+        acts = np.stack([_uniform_actions(2e6, 1e-10, 3e-10)(rng, n, k) for k in range(3)])
+        kw = dict(device_params=stt_default_params(volume=vol), include_thermal_fluctuations=thermal, solver=solver, seed=4,
+                  autoreset=True, max_steps=2)
+        outs = []
+        for layout in ("soa", "records"):
+            env = stg.SpinTorqueVecEnv(n, out_layout=layout, **kw)
+            o0, _ = env.reset(seed=1)
+            rec = [o0.clone()]
+            o, r, te, tr, info = env.step(torch.from_numpy(acts[0]))
+            rec += [o.clone(), r.clone(), te.clone(), tr.clone(), info["status"].clone(), info["final_obs"].clone()]
+            if layout == "records":
+                assert tuple(o.stride()) == (14, 1)
+                buf = torch.full((n, 56), 255, dtype=torch.uint8, device="cuda")
+                o2, r2, te2, tr2, info2 = env.step(torch.from_numpy(acts[1]), out=buf)
+                assert o2.untyped_storage().data_ptr() == buf.untyped_storage().data_ptr()
+                assert torch.equal(record_views(buf)[4], info2["status"]) and bool((buf[:, 55] == 0).all())
+            else:
+                o2, r2, te2, tr2, info2 = env.step(torch.from_numpy(acts[1]))
+            rec += [o2.clone(), r2.clone(), te2.clone(), tr2.clone()]
+            om, rm, tem, trm, im = env.step_many(torch.from_numpy(acts))
+            rec += [om.clone(), rm.clone(), tem.clone(), trm.clone(), im["reward_f64"].clone()]
+            mask = torch.arange(n) % 3 == 0
+            om2, _ = env.reset(seed=5, options={"mask": mask})
+            rec += [om2.clone(), env.get_state()["m"].clone()]
+            outs.append(rec)
+            env.close()
+        for j, (x, y) in enumerate(zip(*outs)):
+            assert torch.equal(x, y), (solver, n, j)
 
 
 @pytest.mark.parametrize("solver", ["rk4", "euler"])
