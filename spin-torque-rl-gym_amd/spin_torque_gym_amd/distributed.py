@@ -165,6 +165,11 @@ class ShardedSpinTorqueVecEnv:
             torch.cuda.current_stream(self.device).wait_event(self._done[k])
         return global_views(self._glob[k]) if unpack else self._glob[k]
 
+    @property
+    def gather_in_flight(self) -> bool:
+        """A gather_begin() is waiting for its gather_end()."""
+        return self._pending is not None
+
     # -- env API ----------------------------------------------------------------------------------------------------
     def _next_slot(self) -> int:
         k = self._slot
@@ -190,15 +195,15 @@ class ShardedSpinTorqueVecEnv:
         self._filled = k
         return self._gather()[0], info
 
-    def step(self, actions, gather: bool = True, actions_are_local: bool = False):
+    def step(self, actions, gather: bool = True, actions_are_local: bool = False, actions_soa: bool = False):
         """One env.step() of this rank's shard, written into its slice of the next global record array.  gather=True
         also runs the exchange and returns the GLOBAL (obs, reward, terminated, truncated, {}); gather=False returns the
         local env's outputs (views of this rank's slice) -- follow with gather_begin()/gather_end() to pipeline."""
         a = torch.as_tensor(actions)
         if not actions_are_local:
-            a = a[self.lo:self.hi]
+            a = a[:, self.lo:self.hi] if actions_soa else a[self.lo:self.hi]
         k = self._next_slot()
-        out = self.local.step(a, out=self._mine(k))
+        out = self.local.step(a, actions_soa=actions_soa, out=self._mine(k))
         self._filled = k
         if not gather:
             return out
