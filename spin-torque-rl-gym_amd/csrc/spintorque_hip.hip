@@ -13,6 +13,7 @@
 #include "stg_kernels.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -222,6 +223,8 @@ static int fail(int code, const std::string& msg) {
             return fail(STG_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
     } while (0)
 
+constexpr int32_t STG_WALK_TILES_DEFAULT = 4;
+
 struct stg_ctx {
     int device;
     int64_t N, env_id0;
@@ -241,7 +244,15 @@ struct stg_ctx {
     double* env_soa = nullptr;        // [STG_NPARAM][N]
     uint8_t *env_type = nullptr, *env_valid = nullptr;
     bool per_env = false;
+    int32_t walk_tiles = STG_WALK_TILES_DEFAULT;   // sorted schedule: tiles an XCD group keeps in flight (stg_slot_block)
 };
+
+static int32_t walk_tiles_from_env() {
+    // experiment knob (A/B runs of the schedule): STG_WALK_TILES=<n>; results never depend on it
+    const char* e = std::getenv("STG_WALK_TILES");
+    const int v = e ? std::atoi(e) : 0;
+    return v > 0 ? v : STG_WALK_TILES_DEFAULT;
+}
 
 static EnvParams env_params_of(const stg_ctx* ctx) {
     EnvParams e{};
@@ -301,6 +312,7 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     stg_ctx* c = new (std::nothrow) stg_ctx();
     if (!c) return fail(STG_E_NOMEM, "out of host memory");
     c->device = device_id; c->N = n_envs; c->env_id0 = env_id0; c->cfg = *cfg;
+    c->walk_tiles = walk_tiles_from_env();
     // one slab: 7 f64 rows, then i32, u32, u8 rows (each row 256-B aligned)
     auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
     const size_t N = (size_t)n_envs;
@@ -485,6 +497,7 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
     }
     a.actions = actions; a.K = K; a.out_every = out_every ? 1 : 0; a.autoreset = autoreset ? 1 : 0;
     a.records = records ? 1 : 0;
+    a.walk = ctx->walk_tiles;
     a.obs = obs; a.final_obs = final_obs; a.reward = reward; a.reward64 = reward_f64; a.energy = energy; a.term = terminated; a.trunc = truncated; a.status = status;
     // the Simple solver only draws a thermal field when temperature > 0 (simple_solver.py:321,378)
     const bool thermal = ctx->cfg.thermal && ctx->cfg.temperature > 0;

@@ -52,6 +52,7 @@ struct StepArgs {
     int32_t force_wg1;
     const void* actions;          // [K][2][N]
     int32_t K, out_every, autoreset;
+    int32_t walk;                 // tiles of an XCD group in flight together (sorted schedule, see stg_slot_block)
     int32_t records;              // STG_OUT_RECORDS: `obs` is the record array [K or 1][N][STG_RECORD_BYTES], reward/term/trunc unused
     const uint32_t* perm;         // lane -> env (duration-sorted schedule) or nullptr
     unsigned long long* counters; // [4]: env-steps, integrator sub-steps/attempts, RHS evaluations, no-op steps
@@ -273,8 +274,13 @@ constexpr int TILE_WAVES = TILE_ENVS / 64;             // = 64 wavefronts of the
 //  * Which wavefronts of a tile share a workgroup (= a CU): with one workgroup per CU, strided ranks u, u+16, u+32, u+48
 //    -- measured 1.96 ms against 2.23 ms for consecutive ranks on the RK45 step at 65 536 envs: four wavefronts that
 //    are busy for the whole launch slow each other down, a long one next to progressively shorter ones does not.
+//  * How many tiles an XCD group has in flight (`walk`).  A tile's 64 wavefronts make scattered 4-8 B accesses over the
+//    tile's whole window of every state/output row (~0.7 MB per tile); the XCD's 4 MB L2 merges them into full lines
+//    only while the windows of all tiles in flight fit into it.  The group therefore walks its tiles `walk` at a time,
+//    rank-major inside such a set (longest wavefronts of the set first): measured at 262 144 mixed envs, all 8 tiles of
+//    a group at once = 363 MB of HBM traffic per launch for 42 MB of algorithmic bytes, see DESIGN.md section 3.
 template <int WGW>
-__device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool sorted, int cw, bool pairs) {
+__device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool sorted, int cw, bool pairs, uint32_t walk) {
     constexpr uint32_t TILE_WGS = TILE_WAVES / WGW;                   // workgroups per tile
     if (!sorted) return (int64_t)b * WGW + cw;
     if (WGW == 1 && pairs && nwg == 1024) {
@@ -291,7 +297,10 @@ __device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool
     if (b >= tiles8 * TILE_WGS) return (int64_t)b * WGW + cw;
     const uint32_t r = b % 8, q = b / 8;                              // XCD group, position inside the group
     const uint32_t tiles_per_xcd = tiles8 / 8;
-    const uint32_t u = q / tiles_per_xcd, t = (q % tiles_per_xcd) * 8 + r;
+    const uint32_t W = walk < tiles_per_xcd ? (walk ? walk : 1u) : tiles_per_xcd;        // tiles walked together
+    const uint32_t set = q / (W * TILE_WGS), within = q % (W * TILE_WGS);
+    const uint32_t Ws = (tiles_per_xcd - set * W) < W ? (tiles_per_xcd - set * W) : W;   // (the last set may be smaller)
+    const uint32_t u = within / Ws, t = (set * W + within % Ws) * 8 + r;
     // one workgroup per CU at most (everything resident from the start): spread; otherwise keep wavefronts of similar
     // duration together, so that a workgroup's four SIMD slots come free together for the next one (measured 6.0 ms
     // against 7.6 ms at 262 144 envs)
@@ -344,7 +353,7 @@ __global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR st
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const bool producer = PC && wave >= WGW;
     const int cw = producer ? (2 * WGW - 1 - wave) : wave;          // the integrating wavefront this one is, or serves
-    const int64_t lane_slot = stg_slot_block<WGW>(blockIdx.x, gridDim.x, a.perm != nullptr, cw, PC) * 64 + lane;
+    const int64_t lane_slot = stg_slot_block<WGW>(blockIdx.x, gridDim.x, a.perm != nullptr, cw, PC, (uint32_t)a.walk) * 64 + lane;
     const bool live = lane_slot < a.N;
     // duration-sorted schedule: slot j of the launch integrates env perm[j], so the 64 lanes of a wavefront have
     // (nearly) equal trip counts; all state and outputs stay at the env's own index
