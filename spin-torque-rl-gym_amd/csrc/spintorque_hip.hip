@@ -223,7 +223,7 @@ static int fail(int code, const std::string& msg) {
             return fail(STG_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
     } while (0)
 
-constexpr int32_t STG_WALK_TILES_DEFAULT = 4;
+constexpr int32_t STG_WALK_TILES_DEFAULT = 1 << 20;   // all tiles of the group (fastest, see stg_slot_block)
 
 struct stg_ctx {
     int device;
