@@ -544,6 +544,9 @@ def roofline_hbm(meas, bytes_per_launch, pmc_row, pmc_src, extra=None):
            "kernel": (pmc_row or {}).get("kernel_name", meas.get("kernel", "stg_step_kernel")), "kernel_ms_avg": round(meas["kernel_ms_avg"], 4),
            "valu_issue_frac": round(ex["valu_issue_frac"], 4) if ex and ex["valu_issue_frac"] is not None else None,
            "pmc_source": pmc_src}
+    if ex and ex["valu_issue_frac"] is not None:
+        # HBM-shaped by its bytes per unit, but say which resource the launch actually sits closer to
+        out["closer_to"] = "valu_issue" if ex["valu_issue_frac"] > out["frac"] else "hbm"
     out.update(extra or {})
     return out
 

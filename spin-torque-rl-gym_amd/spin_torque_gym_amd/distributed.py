@@ -210,6 +210,22 @@ class ShardedSpinTorqueVecEnv:
         obs, reward, term, trunc = self._gather()
         return obs, reward, term, trunc, {}
 
+    def scatter_actions(self, actions=None, src: int = 0, dtype=torch.float32):
+        """A centralised learner's actions -> this rank's shard: `actions` [N_global, 2] on rank `src` (ignored elsewhere),
+        8 B/env over the same links as the gather, in the other direction.  Returns the local [n_local, 2] tensor; pass it
+        to step(..., actions_are_local=True)."""
+        dev = torch.device("cpu") if self._gloo else self.device
+        local = torch.empty((self.n_local, 2), dtype=dtype, device=dev)
+        chunks = None
+        if self.rank == src:
+            a = torch.as_tensor(actions).to(device=dev, dtype=dtype)
+            if tuple(a.shape) != (self.num_envs, 2):
+                raise ValueError(f"expected actions of shape ({self.num_envs}, 2), got {tuple(a.shape)}")
+            chunks = [c.contiguous() for c in a.split(self.n_local)]
+        gsrc = src if self.group is None else dist.get_global_rank(self.group, src)
+        dist.scatter(local, chunks, src=gsrc, group=self.group)
+        return local
+
     def get_performance_stats(self):
         st = self.local.get_performance_stats()
         st["profiler"].update(self.profiler.get_stats())

@@ -67,6 +67,14 @@ def _worker(rank, world, port, n, steps, q):
     for k in range(steps):
         out3 = env3.step(torch.from_numpy(acts[k]))[:4]
         assert all(torch.equal(x, y) for x, y in zip(out3, rec[k + 1]))
+    # a centralised learner: rank 0 scatters the global actions, every rank steps its shard with local actions
+    env4 = ShardedSpinTorqueVecEnv(n, **kw)
+    env4.reset(options={"initial_state": m0, "target_state": tgt})
+    for k in range(steps):
+        loc = env4.scatter_actions(torch.from_numpy(acts[k]) if rank == 0 else None, src=0)
+        assert tuple(loc.shape) == (n // world, 2) and torch.equal(loc, torch.from_numpy(acts[k])[env4.lo:env4.hi])
+        out4 = env4.step(loc, actions_are_local=True)[:4]
+        assert all(torch.equal(x, y) for x, y in zip(out4, rec[k + 1]))
     st = env.get_performance_stats()["profiler"]
     assert st["gather_begin_count"] == steps + 1 and st["step_count"] == steps
     if rank == 0:
