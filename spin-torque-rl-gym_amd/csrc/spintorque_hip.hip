@@ -1,7 +1,7 @@
 // spintorque_hip.hip -- kernels and C-ABI of libspintorque_hip.so (see include/spintorque_hip.h).
 //
 // Layout in HBM (all owned by the context, structure-of-arrays, env index fastest):
-//   mx,my,mz, tx,ty,tz, e_tot : f64[N]   step : i32[N]   rng : u32[N]   done : u8[N]       = 65 B/env
+//   state : EnvRec[N] = { f64 m[3], target[3], e_tot; u32 step | done << 31; u32 rng }        = 64 B/env, one record per env
 //   class table                : f64[n_classes][C_COUNT]  (derived constants, <= 64 classes)
 //   cls                        : u8[N] (caller-owned) when n_classes > 1
 //   per-env parameters         : f64[STG_NPARAM][N] + type/valid u8[N] (library-owned copy), alternative to the class table
@@ -65,16 +65,21 @@ __global__ void __launch_bounds__(64) stg_reset_kernel(const ResetArgs a) {
     const double* row = (a.ncls > 1 || a.ep.soa) ? class_row<true>(a.ctab, a.cls, a.ncls, i, in_range, s_tab, a.ep, a.N) : a.ctab;
     if (!in_range) return;
     const int64_t N = a.N;
+    V3 m0, t0;
+    double etot0;
+    int32_t step0;
+    uint32_t rng0;
+    bool done0;
+    load_state(a.s, i, m0, t0, etot0, step0, rng0, done0);
     if (a.mask && !a.mask[i]) {
         if (a.obs) {   // unchanged env: report its current observation (last action unknown -> 0, as after reset)
-            const V3 m{a.s.mx[i], a.s.my[i], a.s.mz[i]}, t{a.s.tx[i], a.s.ty[i], a.s.tz[i]};
-            if (a.records) write_record(a.obs, i, m, t, row, a.c, a.s.step[i], a.s.etot[i], 0.0, 0.0, 0.0f, 0u);
-            else write_obs(a.obs, N, i, m, t, row, a.c, a.s.step[i], a.s.etot[i], 0.0, 0.0);
+            if (a.records) write_record(a.obs, i, m0, t0, row, a.c, step0, etot0, 0.0, 0.0, 0.0f, 0u);
+            else write_obs(a.obs, N, i, m0, t0, row, a.c, step0, etot0, 0.0, 0.0);
         }
         return;
     }
     V3 m{0, 0, 1}, t{0, 0, 1};
-    device_reset_draw(a.seed, (uint64_t)(a.env_id0 + i), a.s.rng[i], a.c, a.init_m == nullptr, a.target == nullptr, m, t);
+    device_reset_draw(a.seed, (uint64_t)(a.env_id0 + i), rng0, a.c, a.init_m == nullptr, a.target == nullptr, m, t);
     if (a.init_m) {   // device.validate_magnetization (base_device.py:94-116): v / |v|
         const V3 v{a.init_m[i], a.init_m[N + i], a.init_m[2 * N + i]};
         const double n = sqrt(dot(v, v));
@@ -85,11 +90,7 @@ __global__ void __launch_bounds__(64) stg_reset_kernel(const ResetArgs a) {
         const double n = sqrt(dot(v, v));
         t = V3{v.x / n, v.y / n, v.z / n};
     }
-    a.s.mx[i] = m.x; a.s.my[i] = m.y; a.s.mz[i] = m.z;
-    a.s.tx[i] = t.x; a.s.ty[i] = t.y; a.s.tz[i] = t.z;
-    a.s.etot[i] = 0.0;
-    a.s.step[i] = 0;
-    a.s.done[i] = 0;
+    store_state(a.s, i, m, t, 0.0, 0, rng0, false);
     if (a.obs) {
         if (a.records) write_record(a.obs, i, m, t, row, a.c, 0, 0.0, 0.0, 0.0, 0.0f, 0u);
         else write_obs(a.obs, N, i, m, t, row, a.c, 0, 0.0, 0.0, 0.0);
@@ -111,6 +112,37 @@ __global__ void stg_normals_kernel(uint64_t seed, int64_t env_id0, int64_t N, ui
     }
 }
 
+// stg_get_state / stg_set_state: between the library's state records and the caller's component-major arrays
+// (m, target: double[3][N]; the others [N]; any may be NULL = field not copied)
+template <bool SET>
+__global__ void stg_state_copy_kernel(StateView s, int64_t N, double* m, double* target, double* etot, int32_t* step,
+                                      uint32_t* rng, uint8_t* done) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    V3 mm, tt;
+    double e;
+    int32_t st;
+    uint32_t r;
+    bool d;
+    load_state(s, i, mm, tt, e, st, r, d);
+    if (SET) {
+        if (m) mm = V3{m[i], m[N + i], m[2 * N + i]};
+        if (target) tt = V3{target[i], target[N + i], target[2 * N + i]};
+        if (etot) e = etot[i];
+        if (step) st = step[i];
+        if (rng) r = rng[i];
+        if (done) d = done[i] != 0;
+        store_state(s, i, mm, tt, e, st, r, d);
+    } else {
+        if (m) { m[i] = mm.x; m[N + i] = mm.y; m[2 * N + i] = mm.z; }
+        if (target) { target[i] = tt.x; target[N + i] = tt.y; target[2 * N + i] = tt.z; }
+        if (etot) etot[i] = e;
+        if (step) step[i] = st;
+        if (rng) rng[i] = r;
+        if (done) done[i] = d ? 1 : 0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // lane schedule: tile-local counting sort of the envs by this step's integration work (descending)
 // ------------------------------------------------------------------------------------------------
@@ -127,7 +159,7 @@ struct PlanArgs {
     int32_t act_f64;
     int64_t N;
     double max_current, max_duration;
-    const uint8_t* done;      // with skip_done: finished envs go last (no work)
+    const EnvRec* state;      // with skip_done: finished envs go last (no work)
     int32_t skip_done;
     const uint8_t* cls;       // device-physics torque model with several classes: group lanes by device kind
     const double* ctab;
@@ -140,7 +172,7 @@ __device__ __forceinline__ int plan_key(const PlanArgs& a, int64_t i) {
     double J, T;
     if (a.act_f64) parse_action<double>(((const double*)a.actions)[i], ((const double*)a.actions)[a.N + i], a.max_current, a.max_duration, J, T);
     else parse_action<float>(((const float*)a.actions)[i], ((const float*)a.actions)[a.N + i], a.max_current, a.max_duration, J, T);
-    if (a.skip_done && a.done[i]) return (a.by_kind ? PLAN_BUCKETS : PLAN_DUR) - 1;
+    if (a.skip_done && (a.state[i].stepw & STG_DONE_BIT)) return (a.by_kind ? PLAN_BUCKETS : PLAN_DUR) - 1;
     const double w = fmax(T, 1e-10) / a.max_duration;          // below 0.1 ns the RK4 sub-step count stays at ~100
     int b = (int)(w * (PLAN_DUR - 1));
     b = b < 0 ? 0 : (b > PLAN_DUR - 2 ? PLAN_DUR - 2 : b);
@@ -313,22 +345,18 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     if (!c) return fail(STG_E_NOMEM, "out of host memory");
     c->device = device_id; c->N = n_envs; c->env_id0 = env_id0; c->cfg = *cfg;
     c->walk_tiles = walk_tiles_from_env();
-    // one slab: 7 f64 rows, then i32, u32, u8 rows (each row 256-B aligned)
+    // one slab: the state records, the class table, the counter stripes, the lane permutation (each 256-B aligned)
     auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
     const size_t N = (size_t)n_envs;
-    const size_t r8 = al(N * 8), r4 = al(N * 4), r1 = al(N);
-    const size_t total = 7 * r8 + 3 * r4 + r1 + al(sizeof(double) * STG_MAX_CLASSES * C_COUNT) +
+    const size_t rs = al(N * sizeof(EnvRec)), r4 = al(N * 4);
+    const size_t total = rs + r4 + al(sizeof(double) * STG_MAX_CLASSES * C_COUNT) +
                          COUNTER_STRIPES * COUNTER_STRIDE * sizeof(unsigned long long);
     hipError_t e = hipMalloc(&c->slab, total);
     if (e != hipSuccess) { delete c; return fail(STG_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     e = hipMemset(c->slab, 0, total);
     if (e != hipSuccess) { (void)hipFree(c->slab); delete c; return fail(STG_E_HIP, std::string("hipMemset: ") + hipGetErrorString(e)); }
     char* p = (char*)c->slab;
-    double** rows[7] = {&c->s.mx, &c->s.my, &c->s.mz, &c->s.tx, &c->s.ty, &c->s.tz, &c->s.etot};
-    for (auto r : rows) { *r = (double*)p; p += r8; }
-    c->s.step = (int32_t*)p; p += r4;
-    c->s.rng = (uint32_t*)p; p += r4;
-    c->s.done = (uint8_t*)p; p += r1;
+    c->s.rec = (EnvRec*)p; p += rs;
     c->ctab = (double*)p; p += al(sizeof(double) * STG_MAX_CLASSES * C_COUNT);
     c->counters = (unsigned long long*)p; p += COUNTER_STRIPES * COUNTER_STRIDE * sizeof(unsigned long long);
     c->perm = (uint32_t*)p; p += r4;
@@ -486,7 +514,7 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
         PlanArgs pa{};
         pa.actions = actions; pa.act_f64 = act_f64; pa.N = ctx->N;
         pa.max_current = ctx->cfg.max_current; pa.max_duration = ctx->cfg.max_duration;
-        pa.done = ctx->s.done; pa.skip_done = (ctx->cfg.skip_done && !autoreset) ? 1 : 0;
+        pa.state = ctx->s.rec; pa.skip_done = (ctx->cfg.skip_done && !autoreset) ? 1 : 0;
         pa.perm = ctx->perm;
         pa.cls = ctx->cls; pa.ctab = ctx->ctab;
         pa.env_type = ctx->per_env ? ctx->env_type : nullptr;
@@ -583,22 +611,9 @@ int stg_get_state(stg_ctx* ctx, double* m, double* target, double* total_energy,
                   uint8_t* done, void* stream) {
     if (!ctx) return fail(STG_E_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t st = (hipStream_t)stream;
-    const size_t N = (size_t)ctx->N;
-    if (m) {
-        HIP_TRY(hipMemcpyAsync(m, ctx->s.mx, N * 8, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(m + N, ctx->s.my, N * 8, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(m + 2 * N, ctx->s.mz, N * 8, hipMemcpyDeviceToDevice, st));
-    }
-    if (target) {
-        HIP_TRY(hipMemcpyAsync(target, ctx->s.tx, N * 8, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(target + N, ctx->s.ty, N * 8, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(target + 2 * N, ctx->s.tz, N * 8, hipMemcpyDeviceToDevice, st));
-    }
-    if (total_energy) HIP_TRY(hipMemcpyAsync(total_energy, ctx->s.etot, N * 8, hipMemcpyDeviceToDevice, st));
-    if (step_count) HIP_TRY(hipMemcpyAsync(step_count, ctx->s.step, N * 4, hipMemcpyDeviceToDevice, st));
-    if (rng_step) HIP_TRY(hipMemcpyAsync(rng_step, ctx->s.rng, N * 4, hipMemcpyDeviceToDevice, st));
-    if (done) HIP_TRY(hipMemcpyAsync(done, ctx->s.done, N, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(stg_state_copy_kernel<false>, dim3((unsigned)((ctx->N + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       ctx->s, ctx->N, m, target, total_energy, step_count, rng_step, done);
+    HIP_TRY(hipGetLastError());
     return STG_OK;
 }
 
@@ -606,22 +621,10 @@ int stg_set_state(stg_ctx* ctx, const double* m, const double* target, const dou
                   const int32_t* step_count, const uint32_t* rng_step, const uint8_t* done, void* stream) {
     if (!ctx) return fail(STG_E_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t st = (hipStream_t)stream;
-    const size_t N = (size_t)ctx->N;
-    if (m) {
-        HIP_TRY(hipMemcpyAsync(ctx->s.mx, m, N * 8, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(ctx->s.my, m + N, N * 8, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(ctx->s.mz, m + 2 * N, N * 8, hipMemcpyDeviceToDevice, st));
-    }
-    if (target) {
-        HIP_TRY(hipMemcpyAsync(ctx->s.tx, target, N * 8, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(ctx->s.ty, target + N, N * 8, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(ctx->s.tz, target + 2 * N, N * 8, hipMemcpyDeviceToDevice, st));
-    }
-    if (total_energy) HIP_TRY(hipMemcpyAsync(ctx->s.etot, total_energy, N * 8, hipMemcpyDeviceToDevice, st));
-    if (step_count) HIP_TRY(hipMemcpyAsync(ctx->s.step, step_count, N * 4, hipMemcpyDeviceToDevice, st));
-    if (rng_step) HIP_TRY(hipMemcpyAsync(ctx->s.rng, rng_step, N * 4, hipMemcpyDeviceToDevice, st));
-    if (done) HIP_TRY(hipMemcpyAsync(ctx->s.done, done, N, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(stg_state_copy_kernel<true>, dim3((unsigned)((ctx->N + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       ctx->s, ctx->N, const_cast<double*>(m), const_cast<double*>(target), const_cast<double*>(total_energy),
+                       const_cast<int32_t*>(step_count), const_cast<uint32_t*>(rng_step), const_cast<uint8_t*>(done));
+    HIP_TRY(hipGetLastError());
     if (m && target) ctx->have_state = true;
     return STG_OK;
 }

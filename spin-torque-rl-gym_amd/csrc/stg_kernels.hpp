@@ -15,11 +15,22 @@ using namespace stg;
 // ------------------------------------------------------------------------------------------------
 // kernel argument blocks
 // ------------------------------------------------------------------------------------------------
+// One env's persistent state is ONE 64-byte record (env index major): its lane loads and stores it as four 16-byte
+// accesses.  Under the identity schedule a wavefront touches 4 KB contiguous (as coalesced as rows of a structure of
+// arrays); under the duration-sorted schedule, where a lane's env is anywhere in its 4096-env tile, a record is still two
+// whole 32-byte sectors -- ten scattered 1-8 B row elements were ten partially written sectors.
+struct alignas(16) EnvRec {
+    double m[3];
+    double tgt[3];
+    double etot;
+    uint32_t stepw;       // step_count | episode-finished flag in bit 31
+    uint32_t rng;         // stream position: env steps taken since creation (Philox counter word)
+};
+static_assert(sizeof(EnvRec) == 64, "state record size");
+constexpr uint32_t STG_DONE_BIT = 0x80000000u;
+
 struct StateView {
-    double *mx, *my, *mz, *tx, *ty, *tz, *etot;
-    int32_t* step;
-    uint32_t* rng;
-    uint8_t* done;
+    EnvRec* rec;
 };
 
 struct CfgView {
@@ -81,6 +92,29 @@ struct SolveArgs {
 // ------------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_state(const StateView& s, int64_t i, V3& m, V3& tgt, double& etot, int32_t& step,
+                                           uint32_t& rng, bool& done) {
+    const double2* p = reinterpret_cast<const double2*>(s.rec + i);
+    const double2 a = p[0], b = p[1], c = p[2], d = p[3];
+    m = V3{a.x, a.y, b.x};
+    tgt = V3{b.y, c.x, c.y};
+    etot = d.x;
+    const unsigned long long w = (unsigned long long)__double_as_longlong(d.y);
+    const uint32_t sw = (uint32_t)w;
+    step = (int32_t)(sw & ~STG_DONE_BIT);
+    done = (sw & STG_DONE_BIT) != 0u;
+    rng = (uint32_t)(w >> 32);
+}
+__device__ __forceinline__ void store_state(const StateView& s, int64_t i, const V3& m, const V3& tgt, double etot, int32_t step,
+                                            uint32_t rng, bool done) {
+    double2* p = reinterpret_cast<double2*>(s.rec + i);
+    const unsigned long long w = (unsigned long long)((uint32_t)step | (done ? STG_DONE_BIT : 0u)) | ((unsigned long long)rng << 32);
+    p[0] = make_double2(m.x, m.y);
+    p[1] = make_double2(m.z, tgt.x);
+    p[2] = make_double2(tgt.y, tgt.z);
+    p[3] = make_double2(etot, __longlong_as_double((long long)w));
+}
+
 __device__ __forceinline__ void load_env_params(const EnvParams& e, int64_t N, int64_t i, stg_device_params& p) {
     const double* q = e.soa + i;
     int r = 0;
@@ -383,12 +417,12 @@ __global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR st
         return;
     }
 
-    V3 m{a.s.mx[i], a.s.my[i], a.s.mz[i]};          // (lanes without an env read env 0 and never write)
-    V3 tgt{a.s.tx[i], a.s.ty[i], a.s.tz[i]};
-    double etot = a.s.etot[i];
-    int32_t step = a.s.step[i];
-    uint32_t rng = a.s.rng[i];
-    bool done = a.s.done[i] != 0;
+    V3 m, tgt;                                      // (lanes without an env read env 0 and never write)
+    double etot;
+    int32_t step;
+    uint32_t rng;
+    bool done;
+    load_state(a.s, i, m, tgt, etot, step, rng, done);
     const AT* act = (const AT*)a.actions;
     const Recorder norec{};
     unsigned long long c_steps = 0, c_sub = 0, c_noop = 0;
@@ -484,14 +518,7 @@ __global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR st
             if (a.status) a.status[ko * N + i] = st;
         }
     }
-    if (live) {
-        a.s.mx[i] = m.x; a.s.my[i] = m.y; a.s.mz[i] = m.z;
-        a.s.tx[i] = tgt.x; a.s.ty[i] = tgt.y; a.s.tz[i] = tgt.z;
-        a.s.etot[i] = etot;
-        a.s.step[i] = step;
-        a.s.rng[i] = rng;
-        a.s.done[i] = done ? 1 : 0;
-    }
+    if (live) store_state(a.s, i, m, tgt, etot, step, rng, done);
     // on-device metrics (the reference's EnvironmentMonitor/solver stats are host-side bookkeeping): one atomic per
     // counter per wavefront, into one of COUNTER_STRIPES copies
     wave_add3(a.counters + (size_t)((blockIdx.x * WGW + cw) % COUNTER_STRIPES) * COUNTER_STRIDE, s_cnt + cw * 3, c_steps, c_sub, c_noop);
