@@ -115,7 +115,8 @@ typedef struct {
                                        STG_OUT_SOA (0, default): four caller arrays, obs component-major float[12][N];
                                        STG_OUT_RECORDS (1): ONE array of STG_RECORD_BYTES-byte records, env index major --
                                        record i = { float obs[12]; float reward; uint8 terminated, truncated, status, 0 } --
-                                       passed as `obs` (reward/terminated/truncated arguments are ignored, may be NULL).
+                                       passed as `obs` (reward/terminated/truncated arguments are ignored, may be NULL);
+                                       final_obs is then env-major too, float[N][12].
                                        A shard's records are one contiguous block, so the multi-GPU exchange is a single
                                        all-gather straight into the learner's [N_global] record array: obs is then the
                                        [N_global, 12] strided view of it (Gym's own orientation), no transposition or
@@ -203,7 +204,8 @@ int stg_step(stg_ctx* ctx, const void* actions, int32_t act_f64, float* obs, flo
  * autoreset != 0 (same-step auto-reset, the usual GPU vector-env convention): an env whose episode ends at step k
  * reports that step's reward / terminated / truncated, is then reset on the device (as stg_reset with NULL
  * init_m/target, Philox key cfg.seed) and its obs row holds the NEW episode's first observation; final_obs
- * (float[K or 1][12][N], may be NULL) receives the terminal observation of such envs (rows of other envs untouched). */
+ * (float[K or 1][12][N] -- float[K or 1][N][12] with STG_OUT_RECORDS --, may be NULL) receives the terminal observation of
+ * such envs (entries of other envs untouched). */
 int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64, int32_t out_every, int32_t autoreset,
                   float* obs, float* final_obs, float* reward, double* reward_f64, double* energy, uint8_t* terminated,
                   uint8_t* truncated, uint8_t* status, void* stream);

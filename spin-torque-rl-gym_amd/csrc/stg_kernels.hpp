@@ -68,7 +68,7 @@ struct StepArgs {
     const uint32_t* perm;         // lane -> env (duration-sorted schedule) or nullptr
     unsigned long long* counters; // [4]: env-steps, integrator sub-steps/attempts, RHS evaluations, no-op steps
     float* obs;                   // [K or 1][12][N]
-    float* final_obs;             // [K or 1][12][N] or nullptr: terminal observation of envs auto-reset at that step
+    float* final_obs;             // [K or 1][12][N] (records: [K or 1][N][12]) or nullptr: terminal observation of envs auto-reset at that step
     float* reward;                // [K or 1][N]
     double *reward64, *energy;
     uint8_t *term, *trunc, *status;
@@ -497,7 +497,17 @@ __global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR st
         // device and the observation handed to the agent is the NEW episode's first one (the terminal observation goes
         // to final_obs when the caller asked for it)
         const bool do_reset = a.autoreset && done && live;
-        if (wr && do_reset && a.final_obs) write_obs(a.final_obs + ko * 12 * N, N, i, m, tgt, row, a.c, step, etot, J, T);
+        if (wr && do_reset && a.final_obs) {
+            if (a.records) {      // env-major float[N][12]: one 48-byte block per env
+                float o[12];
+                make_obs(o, m, tgt, row, a.c, step, etot, J, T);
+                float2* fo = (float2*)(a.final_obs + (ko * N + i) * 12);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) fo[q] = make_float2(o[2 * q], o[2 * q + 1]);
+            } else {
+                write_obs(a.final_obs + ko * 12 * N, N, i, m, tgt, row, a.c, step, etot, J, T);
+            }
+        }
         if (do_reset) {
             device_reset_draw(a.c.seed, env_id, rng, a.c, true, true, m, tgt);
             etot = 0.0; step = 0; done = false;

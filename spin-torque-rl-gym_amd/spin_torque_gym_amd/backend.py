@@ -147,7 +147,8 @@ class HipBackend:
         self.reward64 = torch.empty(n, dtype=torch.float64, device=dev)
         self.energy = torch.empty(n, dtype=torch.float64, device=dev)
         self.status = torch.empty(n, dtype=torch.uint8, device=dev)
-        self.final_obs = None                 # [12,N], allocated on the first auto-resetting step
+        self.final_obs = None                 # [12,N] (a view of [N,12] in the records layout), allocated on the first auto-resetting step
+        self._final_buf = None
 
     # -- plumbing -------------------------------------------------------------------------------
     def _stream(self):
@@ -223,13 +224,17 @@ class HipBackend:
         f64 = a.dtype == torch.float64
         a = self._dev(a, torch.float64 if f64 else torch.float32, (2, self.n))
         if autoreset and self.final_obs is None:
-            self.final_obs = torch.zeros((12, self.n), dtype=torch.float32, device=self.device)
+            if self.records_layout:           # env-major like the records: one 48-byte block per env
+                self._final_buf = torch.zeros((self.n, 12), dtype=torch.float32, device=self.device)
+                self.final_obs = self._final_buf.t()
+            else:
+                self._final_buf = self.final_obs = torch.zeros((12, self.n), dtype=torch.float32, device=self.device)
         if self.records_layout:
             rec = self.packed if out is None else out
             if rec.dtype != torch.uint8 or tuple(rec.shape) != (self.n, RECORD_BYTES) or not rec.is_contiguous() or rec.device != self.device:
                 raise ValueError(f"out must be a contiguous uint8 [{self.n}, {RECORD_BYTES}] tensor on {self.device}")
             _lib.check(self.lib.stg_step_many(self._ctx, 1, _ptr(a), int(f64), 1, int(bool(autoreset)), _ptr(rec),
-                                              _ptr(self.final_obs) if autoreset else None, None, _ptr(self.reward64),
+                                              _ptr(self._final_buf) if autoreset else None, None, _ptr(self.reward64),
                                               _ptr(self.energy), None, None, _ptr(self.status), self._stream()))
             self._keep = (a,)
             if out is None:
@@ -267,9 +272,16 @@ class HipBackend:
         reward64 = torch.empty((ko, n), dtype=torch.float64, device=dev)
         status = torch.empty((ko, n), dtype=torch.uint8, device=dev)
         self.energy_many = torch.empty((ko, n), dtype=torch.float64, device=dev)
-        self.final_obs_many = torch.zeros((ko, 12, n), dtype=torch.float32, device=dev) if autoreset else None
+        fbuf = None
+        self.final_obs_many = None
+        if autoreset:
+            if self.records_layout:
+                fbuf = torch.zeros((ko, n, 12), dtype=torch.float32, device=dev)
+                self.final_obs_many = fbuf.transpose(1, 2)
+            else:
+                fbuf = self.final_obs_many = torch.zeros((ko, 12, n), dtype=torch.float32, device=dev)
         _lib.check(self.lib.stg_step_many(self._ctx, K, _ptr(a), int(f64), int(bool(out_every)), int(bool(autoreset)),
-                                          _ptr(out_ptr), _ptr(self.final_obs_many), None if self.records_layout else _ptr(reward),
+                                          _ptr(out_ptr), _ptr(fbuf), None if self.records_layout else _ptr(reward),
                                           _ptr(reward64), _ptr(self.energy_many), None if self.records_layout else _ptr(term),
                                           None if self.records_layout else _ptr(trunc), _ptr(status), self._stream()))
         self._keep = (a,)

@@ -113,8 +113,11 @@ class SpinTorqueVecEnv:
 
     Device classes: pass one ``device_type``/``device_params`` for a homogeneous batch, or lists of both plus
     ``class_index`` (uint8 per env) for mixed batches (up to 64 classes; the per-class constants live in LDS).
-    Layout: ``obs`` is returned as an [N,12] *view* of the kernel's component-major [12,N] buffer (no copy);
-    actions are accepted as [N,2] (Gym convention) or, with ``actions_soa=True``, as the kernel's [2,N].
+    Layout: with ``out_layout='records'`` (default) the kernel writes one 56-byte record per env -- obs[12] f32, reward f32,
+    terminated, truncated, status -- and ``obs`` / ``reward`` / the flags are strided *views* of that array (``obs`` is [N,12],
+    row stride 14 floats); ``out_layout='soa'`` keeps four separate arrays with a component-major [12,N] obs buffer, of which
+    ``obs`` is the transposed view.  No copies either way.  Actions are accepted as [N,2] (Gym convention) or, with
+    ``actions_soa=True``, as the kernel's [2,N].
     """
 
     def __init__(self, num_envs: int, device_type: Union[str, Sequence[str]] = "stt_mram",
@@ -126,7 +129,7 @@ class SpinTorqueVecEnv:
                  autoreset: bool = False, skip_done: bool = False, device_index: int = 0, env_id0: int = 0,
                  max_attempts: int = 200_000, lane_sort: Optional[bool] = None, wave_spec: Optional[bool] = None, torque_model: str = "reference",
                  noise_model: str = "white", correlation_time: float = 1e-12,
-                 per_env_params: Optional[Dict[str, Any]] = None, out_layout: str = "soa",
+                 per_env_params: Optional[Dict[str, Any]] = None, out_layout: str = "records",
                  backend=None):
         self.num_envs = int(num_envs)
         factory = DeviceFactory()
