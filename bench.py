@@ -438,6 +438,10 @@ def collect_pmc_live(argv):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        # this process is itself being profiled (its GPU is initialised by the profiler's preloaded library already, and a
+        # profiler inside a profiler measures nothing useful): no child passes
+        return None, "running under a profiler: no nested passes"
     if not os.path.exists("/dev/kfd"):
         return None, "no GPU device node"
     work = tempfile.mkdtemp(prefix="stg_pmc_", dir="/tmp")
