@@ -658,8 +658,8 @@ def main():
                                f"solver={args.solver} ({'LLGSSolver SciPy-RK45 rtol1e-6 atol1e-9 max_step 1ps' if args.solver == 'rk45' else 'SimpleLLGSSolver fixed-step dt<=1ps'}), "
                                f"full env.step, J~U[-2e6,2e6], pulse~U[0.1,1]ns f32, volume={volume_for(args.solver):g}, autoreset",
                    "envs_per_gpu": n_local, "global_envs": n_total, "solver": args.solver, "thermal": bool(args.thermal),
-                   "parallelism": (f"env-sharded x{world}; per step ONE in-place {args.gather_algo} of 56 B/env records into the global "
-                                   f"record array, pipelined under the next kernel; the timed loop hands out the learner's typed views "
+                   "parallelism": (f"env-sharded x{world}; per step ONE {args.gather_algo} of 56 B/env records (written by the step kernel straight into the send buffer) into the "
+                                   f"global record array, pipelined under the next kernel; the timed loop hands out the learner's typed views "
                                    f"(obs [N,12], reward, terminated, truncated) -- no copies") if world > 1 else "single GPU"},
         "roofline": roofline_step(meas, n_local, args.solver, False, row("headline"), pmc_src),
     }

@@ -6,13 +6,15 @@ them with its own `stg_ctx` (Philox counters use the GLOBAL env index, so result
 The only communication is what an RL learner needs -- the step's (obs, reward, terminated, truncated) of every env.
 
 Copy-free by layout.  The step kernel writes its outputs as 56-byte env-major RECORDS (`out_layout='records'`,
-include/spintorque_hip.h: STG_OUT_RECORDS) straight into this rank's slice of a GLOBAL record array uint8[N_global, 56];
-ONE in-place all-gather (RCCL over xGMI when the backend is "nccl"; the CPU tests run the same code over gloo) fills in
-the other ranks' slices, and what the learner gets are typed strided VIEWS of that array -- obs float32 [N_global, 12]
-(Gym's orientation), reward float32 [N_global], terminated / truncated bool [N_global].  No staging copy before the
-collective, no transposition or `torch.cat` after it.  Two global arrays alternate, so the gather of step k runs on its
-own HIP stream under the kernel of step k+1 (`gather_begin` / `gather_end`), which writes the other array.
-At 131 072 envs per GPU a rank contributes 7.3 MB per step.
+include/spintorque_hip.h: STG_OUT_RECORDS) straight into the collective's send buffer -- a shard's records are one
+contiguous block -- and ONE all-gather (RCCL over xGMI when the backend is "nccl"; the CPU tests run the same code over
+gloo) assembles the GLOBAL record array uint8[N_global, 56]; what the learner gets are typed strided VIEWS of that array --
+obs float32 [N_global, 12] (Gym's orientation), reward float32 [N_global], terminated / truncated bool [N_global].  No
+staging copy before the collective, no transposition or `torch.cat` after it.  Two send buffers and two global arrays
+alternate, so the gather of step k runs on its own HIP stream under the kernel of step k+1 (`gather_begin` /
+`gather_end`), which writes the other pair.  At 131 072 envs per GPU a rank contributes 7.3 MB per step.
+(`inplace=True` makes the send buffer this rank's slice of the global array itself -- NCCL/RCCL's in-place all-gather
+form; the point-to-point exchange always works that way.)
 
 `gather_algo`: "all_gather" (default) = `all_gather_into_tensor`, RCCL picks the algorithm; "p2p" = one grouped batch of
 7 sends + 7 receives per rank (`batch_isend_irecv`), every peer's slice over its own xGMI link at once -- the one-shot
@@ -49,7 +51,7 @@ class ShardedSpinTorqueVecEnv:
     """`num_envs` global environments sharded over the ranks of `group` (default: the world group)."""
 
     def __init__(self, num_envs: int, group: Optional[dist.ProcessGroup] = None, device_index: Optional[int] = None,
-                 class_index=None, gather_algo: str = "all_gather", **env_kwargs):
+                 class_index=None, gather_algo: str = "all_gather", inplace: bool = False, **env_kwargs):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised (backend 'nccl' = RCCL on ROCm, or 'gloo')")
         if gather_algo not in ("all_gather", "p2p"):
@@ -75,6 +77,11 @@ class ShardedSpinTorqueVecEnv:
         # two global record arrays: the kernel of step k writes this rank's slice of array k & 1 while the gather of
         # step k-1 (array (k-1) & 1) may still be in flight
         self._glob = [torch.zeros((self.num_envs, RECORD_BYTES), dtype=torch.uint8, device=dev) for _ in range(2)]
+        # where the step kernel writes: the slice of the global array itself (p2p / in-place all-gather), or a send buffer
+        # of its own (the plain out-of-place all-gather, the most travelled path through RCCL)
+        self._inplace = bool(inplace) or gather_algo == "p2p"
+        self._send = None if self._inplace else [torch.zeros((self.n_local, RECORD_BYTES), dtype=torch.uint8, device=dev)
+                                                 for _ in range(2)]
         self._slot = 0            # array the NEXT step writes
         self._filled = None       # array holding the last step's local records, not yet gathered
         self._pending = None
@@ -87,10 +94,11 @@ class ShardedSpinTorqueVecEnv:
 
     # -- the collective ---------------------------------------------------------------------------------------------
     def _mine(self, k: int) -> torch.Tensor:
-        return self._glob[k][self.lo:self.hi]
+        """The record array of slot k that this rank's step kernel writes and the exchange sends."""
+        return self._glob[k][self.lo:self.hi] if self._inplace else self._send[k]
 
     def _exchange(self, k: int) -> None:
-        """Fills the other ranks' slices of global array k (this rank's slice holds its records already)."""
+        """Assembles global array k from every rank's records of slot k."""
         g, mine = self._glob[k], self._mine(k)
         if self._gloo:
             # CPU tests / single-GPU rehearsal: gloo moves host memory and is not an in-place collective
@@ -120,7 +128,7 @@ class ShardedSpinTorqueVecEnv:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()            # (stream-ordered on NCCL/RCCL: does not block the host)
             return
-        # in place: the send buffer is this rank's slice of the receive buffer (NCCL/RCCL's in-place all-gather form)
+        # (in-place form: the send buffer is this rank's slice of the receive buffer, NCCL/RCCL's in-place all-gather)
         dist.all_gather_into_tensor(g.view(-1), mine.reshape(-1), group=self.group)
 
     def _gather(self, unpack: bool = True):

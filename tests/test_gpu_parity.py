@@ -876,9 +876,9 @@ def test_integration_md_ctypes_stub_runs(stg):
 
 def test_pipelined_gather_overlaps_and_matches_sync(stg):
     """ShardedSpinTorqueVecEnv through RCCL with a world of one rank (the 8-GPU run is the driver's): the step kernel
-    writes 56-byte records straight into this rank's slice of the global record array, the in-place all-gather runs on
-    its own stream under the next step's kernel (gather_begin/gather_end, two arrays alternating), and the learner gets
-    typed strided views -- no staging copy, no torch.cat.  Pipelined == synchronous == the plain single-GPU env, bit for
+    writes 56-byte records straight into the collective's send buffer (or, in-place / p2p, into this rank's slice of the
+    global record array), the all-gather runs on its own stream under the next step's kernel (gather_begin/gather_end,
+    two buffer pairs alternating), and the learner gets typed strided views -- no staging copy, no torch.cat.  Pipelined == synchronous == the plain single-GPU env, bit for
     bit, for the all-gather and for the point-to-point exchange."""
     import socket
     import torch.distributed as dist
@@ -897,9 +897,9 @@ def test_pipelined_gather_overlaps_and_matches_sync(stg):
             o, r, te, tr, _ = plain.step(a)
             want.append((o.clone(), r.clone(), te.clone(), tr.clone()))
         plain.close()
-        for algo in ("all_gather", "p2p"):
-            e1 = ShardedSpinTorqueVecEnv(n, gather_algo=algo, **kw); e1.reset(seed=2, gather=False)
-            e2 = ShardedSpinTorqueVecEnv(n, gather_algo=algo, **kw); e2.reset(seed=2, gather=False)
+        for algo, inplace in (("all_gather", False), ("all_gather", True), ("p2p", False)):
+            e1 = ShardedSpinTorqueVecEnv(n, gather_algo=algo, inplace=inplace, **kw); e1.reset(seed=2, gather=False)
+            e2 = ShardedSpinTorqueVecEnv(n, gather_algo=algo, inplace=inplace, **kw); e2.reset(seed=2, gather=False)
             sync = []
             for a in acts:
                 o, r, te, tr, _ = e1.step(a)
