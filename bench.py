@@ -355,7 +355,7 @@ def row_specs(args):
              262144, "rk4", 0, True, "device")):
         if solver == args.solver and n == args.envs_per_gpu and bool(thermal) == bool(args.thermal) and not mixed:
             continue
-        rows.append((name, dict(kind="step", n=n, solver=solver, thermal=thermal, mixed=mixed, tm=tm, steps=st, warmup=1,
+        rows.append((name, dict(kind="step", n=n, solver=solver, thermal=thermal, mixed=mixed, tm=tm, steps=st, warmup=2,
                                 lane_sort=None, wave_spec=None)))
     for K in (1, 8):
         rows.append((f"cfg2a K={K}", dict(kind="short", n=1048576, K=K, steps=st)))
