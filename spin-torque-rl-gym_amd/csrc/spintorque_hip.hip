@@ -283,7 +283,10 @@ static int32_t walk_tiles_from_env() {
     // experiment knob (A/B runs of the schedule): STG_WALK_TILES=<n>; results never depend on it
     const char* e = std::getenv("STG_WALK_TILES");
     const int v = e ? std::atoi(e) : 0;
-    return v > 0 ? v : STG_WALK_TILES_DEFAULT;
+    int32_t w = v > 0 ? v : STG_WALK_TILES_DEFAULT;
+    const char* sn = std::getenv("STG_SNAKE");       // unset: automatic (see stg_slot_block)
+    if (sn) w |= (int32_t)(std::atoi(sn) != 0 ? STG_WALK_SNAKE_ON : STG_WALK_SNAKE_OFF);
+    return w;
 }
 
 static EnvParams env_params_of(const stg_ctx* ctx) {

@@ -313,6 +313,7 @@ constexpr int TILE_WAVES = TILE_ENVS / 64;             // = 64 wavefronts of the
 //    only while the windows of all tiles in flight fit into it.  The group therefore walks its tiles `walk` at a time,
 //    rank-major inside such a set (longest wavefronts of the set first): measured at 262 144 mixed envs, all 8 tiles of
 //    a group at once = 363 MB of HBM traffic per launch for 42 MB of algorithmic bytes, see DESIGN.md section 3.
+constexpr uint32_t STG_WALK_SNAKE_ON = 0x40000000u, STG_WALK_SNAKE_OFF = 0x20000000u;      // flag bits in `walk`
 template <int WGW>
 __device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool sorted, int cw, bool pairs, uint32_t walk) {
     constexpr uint32_t TILE_WGS = TILE_WAVES / WGW;                   // workgroups per tile
@@ -329,8 +330,23 @@ __device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool
     }
     const uint32_t tiles8 = (nwg / (8 * TILE_WGS)) * 8;              // tiles in complete groups of 8
     if (b >= tiles8 * TILE_WGS) return (int64_t)b * WGW + cw;
-    const uint32_t r = b % 8, q = b / 8;                              // XCD group, position inside the group
+    const uint32_t r = b % 8;                                         // XCD group
+    uint32_t q = b / 8;                                               // position inside the group
     const uint32_t tiles_per_xcd = tiles8 / 8;
+    {
+        // Boustrophedon order over the XCD's 32 CUs.  The dispatcher deals a group's workgroups to its CUs in rounds of 32;
+        // when every workgroup is resident from the start (at most two rounds: every kernel fits two workgroups per CU) the
+        // assignment is static, and with the plain longest-first order CU j gets the j-th longest workgroup of BOTH rounds
+        // (131 072 envs: 1.5 work units on the first CUs, 0.6 on the last).  Reversing the second round gives every CU the
+        // same sum: RK45 + thermal at 131 072 envs 4.03 -> 3.09 ms, RK4 + thermal 0.95 -> 0.77 ms.  With more rounds the
+        // later workgroups go to whichever CU frees up first, where longest-first is the better order (262 144 envs:
+        // 5.61 ms against 6.00 ms reversed) -- so: two rounds at most (STG_SNAKE=0/1 forces it off/on for experiments).
+        const uint32_t n_q = tiles_per_xcd * TILE_WGS, round = q / 32u, p = q % 32u;
+        const bool snake = (walk & STG_WALK_SNAKE_ON) ? true : ((walk & STG_WALK_SNAKE_OFF) ? false : n_q <= 64u);
+        const uint32_t len = (n_q - round * 32u) < 32u ? (n_q - round * 32u) : 32u;
+        if (snake && (round & 1u)) q = round * 32u + (len - 1u - p);
+    }
+    walk &= ~(STG_WALK_SNAKE_ON | STG_WALK_SNAKE_OFF);
     const uint32_t W = walk < tiles_per_xcd ? (walk ? walk : 1u) : tiles_per_xcd;        // tiles walked together
     const uint32_t set = q / (W * TILE_WGS), within = q % (W * TILE_WGS);
     const uint32_t Ws = (tiles_per_xcd - set * W) < W ? (tiles_per_xcd - set * W) : W;   // (the last set may be smaller)

@@ -1194,7 +1194,7 @@ def test_switching_statistics_independent_streams(stg):
         assert abs(a_ - b_) <= 4 * sigma + 1e-3, (a_, b_, sigma)
 
 
-@pytest.mark.parametrize("n", [65537, 70001, 131072 + 4096 + 77, 300000])
+@pytest.mark.parametrize("n", [65537, 70001, 100000, 131072, 131072 + 4096 + 77, 300000])
 def test_schedule_covers_every_env_exactly_once(stg, n):
     """Launch sizes that take the 4-wavefront workgroups with ragged tiles: the sorted, XCD-aware schedule (and the
     workgroup composition rules) must step every env exactly once -- same results as the identity schedule, bit for bit,
