@@ -172,6 +172,37 @@ def test_cfg3_headline_rk45_thermal_65536_vs_oracle_slices(stg):
     assert torch.all(torch.abs(norm - 1) < 1e-14)
 
 
+def test_cfg5_shard_rk45_thermal_131072_vs_oracle_slices(stg):
+    """One cfg5 shard (1 048 576 envs over 8 GPUs = 131 072 per GPU) of the headline workload, keyed as rank 3's shard
+    (env_id0 = 3 x 131 072): the 4-wavefront thermal RK45 kernel without wave specialisation, two rounds of workgroups
+    per CU -- the boustrophedon order of the sorted schedule (csrc/stg_kernels.hpp: stg_slot_block)."""
+    n, id0 = 131072, 3 * 131072
+    m0, tgt, acts = _inputs(n, seed=77, steps=2)
+    kw = dict(device_params=stt_default_params(volume=9.7e-6), include_thermal_fluctuations=True, temperature=300.0,
+              solver="rk45", seed=1234, autoreset=True)
+    hip, c = _run_hip(stg, n, m0, tgt, acts, env_id0=id0, **kw)
+    assert c["env_steps"] == 2 * n and c["noop_steps"] == 0
+    worst = 0.0
+    for s0 in _slice_starts(n)[::2]:
+        from helpers import OracleBackend
+        sl = slice(s0, s0 + SLICE)
+        env = stg.SpinTorqueVecEnv(SLICE, env_id0=id0 + s0, backend=OracleBackend, **kw)
+        env.reset(options={"initial_state": m0[sl], "target_state": tgt[sl]})
+        ora = []
+        for a in acts:
+            o, r, te, tr, info = env.step(torch.from_numpy(a[sl]))
+            st = env.get_state()
+            ora.append(dict(obs=o.t().clone(), reward=info["reward_f64"].clone(), term=te.clone(), trunc=tr.clone(),
+                            status=info["status"].clone(), energy=info["energy"].clone(), m=st["m"].clone(),
+                            step_count=st["step_count"].clone(), final_obs=info["final_obs"].t().clone()))
+        env.close()
+        worst = max(worst, _cmp_slice(hip, ora, slice(s0, s0 + SLICE), TOL_RK45, ("cfg5 shard", s0)))
+    print("cfg5 shard (rk45, thermal, 131072, env_id0 = 393216): worst |dm| vs oracle on slices =", worst)
+    other, c2 = _run_hip(stg, n, m0, tgt, acts, env_id0=id0, **kw, lane_sort=False)
+    _assert_same_bits(hip, other, "cfg5 shard lane_sort off")
+    assert c2 == c
+
+
 def test_cfg3_rk4_thermal_65536_vs_oracle_slices(stg):
     """The env's own solver at the headline size (bench.py `also`: cfg3 rk4): RK4 producer/consumer kernel with the
     handshake-word protocol, nwg == 1024 slot map."""

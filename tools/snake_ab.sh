@@ -1,8 +1,8 @@
 #!/bin/bash
-# A/B of the boustrophedon workgroup order (STG_SNAKE: 0 off, 1 on, unset = automatic) on the throughput launches
-for cfg in "131072 rk45 1" "131072 rk4 1" "131072 rk4 0" "98304 rk45 1" "98304 rk4 0" "262144 rk45 1"; do
+# A/B of the boustrophedon workgroup order (STG_SNAKE: 0 off, 1 on, unset = automatic): usage tools/snake_ab.sh "<envs solver thermal>" ...
+for cfg in "$@"; do
   set -- $cfg
-  for rep in 1 2; do for sn in 0 auto; do
+  for rep in 1 2; do for sn in 0 1 auto; do
     if [ $sn = auto ]; then unset STG_SNAKE; else export STG_SNAKE=$sn; fi
     timeout -k 10 200 python3 bench.py --steps 8 --warmup 2 --cpu-baseline 0 --also 0 --pmc off --envs-per-gpu $1 --solver $2 --thermal $3 2>/dev/null | python3 -c "
 import json,sys
