@@ -444,3 +444,60 @@ def test_cfg3_switching_statistics_well_conditioned_volume(stg):
             mixed += int(0.02 < s_c < 0.98)
         assert mixed >= 4, (solver, mixed)
 
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# SpinTorqueArray-v0 at the benchmarked size (bench.py run_array_config: 262 144 arrays of 4 x 4 cells)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["individual", "global"])
+def test_array_env_262144_vs_oracle_slices(stg, mode):
+    """Both array kernels bench.py times (the streaming 'individual' kernel and the LDS-staged general one in 'global' mode),
+    262 144 arrays, bench.py's action distribution, two steps: slices of 64 arrays against the oracle, whole batch repeatable."""
+    from helpers import OracleArrayBackend
+    n, size = 262144, (4, 4)
+    ndev = size[0] * size[1]
+    rng = np.random.default_rng(31)
+    v = rng.normal(0, 1, (n, size[0], size[1], 3))
+    init = v / np.linalg.norm(v, axis=-1, keepdims=True)
+    a_dim = 2 if mode == "global" else 3
+    acts = np.empty((2, n, a_dim), dtype=np.float32)
+    if mode == "global":
+        acts[..., 0] = rng.uniform(-2e6, 2e6, (2, n)); acts[..., 1] = rng.uniform(-2e6, 2e6, (2, n))
+    else:
+        acts[..., 0] = rng.uniform(0, ndev, (2, n)); acts[..., 1] = rng.uniform(-2e6, 2e6, (2, n))
+        acts[..., 2] = rng.uniform(1e-10, 1e-9, (2, n))
+    kw = dict(action_mode=mode, max_steps=10**6, success_threshold=2.0)
+    runs = []
+    for rep in range(2):
+        env = stg.SpinTorqueArrayVecEnv(n, size, seed=3, **kw)
+        obs, _ = env.reset(options={"initial_pattern": init})
+        rec = [obs.clone()]
+        for a in acts:
+            obs, r, te, tr, info = env.step(torch.from_numpy(a))
+            rec.append((obs.clone(), info["reward_f64"].clone(), te.clone(), tr.clone(), info["energy"].clone(),
+                        env.get_state()["pattern"].clone()))
+        env.close()
+        runs.append(rec)
+    assert torch.equal(runs[0][0], runs[1][0])
+    for x, y in zip(runs[0][1:], runs[1][1:]):
+        assert all(torch.equal(p, q) for p, q in zip(x, y))
+    hip = runs[0]
+    worst = 0.0
+    for s0 in _slice_starts(n)[::2]:
+        sl = slice(s0, s0 + SLICE)
+        env = stg.SpinTorqueArrayVecEnv(SLICE, size, backend=OracleArrayBackend, **kw)
+        obs, _ = env.reset(options={"initial_pattern": init[sl]})
+        assert np.allclose(hip[0][sl].cpu().numpy(), obs.numpy(), rtol=2e-7, atol=1e-12)
+        for k, a in enumerate(acts):
+            obs, r, te, tr, info = env.step(torch.from_numpy(a[sl]))
+            h = hip[k + 1]
+            pat = env.get_state()["pattern"].numpy()
+            d = np.abs(h[5][:, sl].cpu().numpy() - pat).max()
+            worst = max(worst, d)
+            assert d <= 1e-11, (mode, s0, k, d)
+            assert np.allclose(h[0][sl].cpu().numpy(), obs.numpy(), rtol=3e-7, atol=1e-10)
+            assert np.allclose(h[1][sl].cpu().numpy(), info["reward_f64"].numpy(), rtol=1e-9, atol=1e-9)
+            assert np.array_equal(h[2][sl].cpu().numpy(), te.numpy()) and np.array_equal(h[3][sl].cpu().numpy(), tr.numpy())
+            assert np.allclose(h[4][sl].cpu().numpy(), info["energy"].numpy(), rtol=1e-10, atol=0)
+        env.close()
+    print(f"array env ({mode}, 262144 arrays): worst |dm| vs oracle on slices =", worst)
