@@ -453,9 +453,20 @@ def collect_pmc_live(argv):
             outdir, mani = os.path.join(work, tag), os.path.join(work, tag + ".json")
             cmd = [exe, "--kernel-trace", "--pmc", *ctrs.split(), "--output-format", "csv", "-d", outdir, "--",
                    sys.executable, os.path.abspath(__file__), *argv, "--pmc-child", mani, "--cpu-baseline", "0"]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
-            if r.returncode != 0 or not os.path.exists(mani):
-                return None, f"pass '{tag}' failed (rc {r.returncode}): {r.stdout.decode(errors='replace')[-300:]}"
+            # own process group, so that a pass that hangs is killed together with the program it profiles (nothing may be
+            # left on the GPU when the timed runs start)
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
+            try:
+                log, _ = proc.communicate(timeout=300)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, 9)
+                except OSError:
+                    pass
+                proc.wait()
+                return None, f"pass '{tag}' timed out"
+            if proc.returncode != 0 or not os.path.exists(mani):
+                return None, f"pass '{tag}' failed (rc {proc.returncode}): {log.decode(errors='replace')[-300:]}"
             for key, v in parse_pmc_csv(outdir, json.load(open(mani))).items():
                 e = merged.setdefault(key, {"kernel_name": v["kernel_name"], "counters": {}})
                 e["counters"].update(v["counters"])
