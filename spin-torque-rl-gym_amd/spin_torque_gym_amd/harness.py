@@ -9,7 +9,6 @@
 import time
 from typing import Any, Dict
 
-import numpy as np
 import torch
 
 from .envs import SpinTorqueEnv, SpinTorqueVecEnv

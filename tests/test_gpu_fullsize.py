@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import sot_default_params, stt_default_params, vcma_default_params
+from conftest import stt_default_params
 
 pytestmark = pytest.mark.gpu
 
@@ -344,7 +344,6 @@ def _oracle_bins(solver, vol, m0_rows, bins, seed, per_bin=None):
     per_bin = STAT_N if per_bin is None else per_bin
     import ctypes as C
     import oracle
-    from helpers import make_states  # noqa: F401  (same state layout)
     n = len(bins) * per_bin
     p = (oracle.Params * 1)(oracle.make_params(stt_default_params(volume=vol)))
     c = oracle.make_config(solver=solver, thermal=True, seed=seed)
