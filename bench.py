@@ -248,8 +248,22 @@ def run_config(n_local, solver, thermal, steps, warmup, rank, world, device_inde
     c = backend.counters()
     # SURVEY 8e "report both": a learner that is data-parallel over the same ranks needs no gather at all
     wall_ng = timed_block(gather=False)[0] if (world > 1 and retime) else None
+    gather_only_ms = None
+    if world > 1 and retime:
+        # the collective by itself (nothing to hide under): `steps` exchanges of the last step's records back to back
+        env.step(acts[warmup], gather=False, actions_are_local=True, actions_soa=True)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            env.gather_again()                       # (re-send the records of the step above)
+            env.gather_begin()
+            env.gather_end()
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        gather_only_ms = (time.perf_counter() - t0) / steps * 1e3
     env.close()
-    return dict(wall_no_gather_s=wall_ng, wall_s=wall, device_span_s=dev_span, blocks_timed=blocks, kernel_ms_avg=float(np.mean(kern_ms)), kernel_ms_min=float(np.min(kern_ms)),
+    return dict(gather_only_ms=gather_only_ms, wall_no_gather_s=wall_ng, wall_s=wall, device_span_s=dev_span, blocks_timed=blocks, kernel_ms_avg=float(np.mean(kern_ms)), kernel_ms_min=float(np.min(kern_ms)),
                 env_steps=c["env_steps"], work_units=c["work_units"], noop_steps=c["noop_steps"], launches=steps, warmup=warmup)
 
 
@@ -681,6 +695,11 @@ def main():
         out["no_gather"] = {"value": round(n_total * args.steps / float(wng.item()), 1), "unit": "env-steps/s",
                             "ms_per_step": round(float(wng.item()) / args.steps * 1e3, 4),
                             "note": "same run without the per-step all-gather (learner data-parallel over the same ranks)"}
+        gm = torch.tensor([meas["gather_only_ms"]], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(gm, op=dist.ReduceOp.MAX)
+        out["gather_only"] = {"ms": round(float(gm.item()), 4), "bytes_per_rank": 56 * n_local, "algo": args.gather_algo,
+                              "note": "the exchange by itself, back to back with nothing to hide under (max over ranks); in the "
+                                      "timed loop it runs on its own stream under the next step's kernel"}
     if rank == 0 and world == 1 and args.also:
         also = []
         for key, spec in specs[1:]:

@@ -84,6 +84,7 @@ class ShardedSpinTorqueVecEnv:
                                                  for _ in range(2)]
         self._slot = 0            # array the NEXT step writes
         self._filled = None       # array holding the last step's local records, not yet gathered
+        self._last = None         # ... whether gathered or not (gather_again)
         self._pending = None
         self._gloo = dist.get_backend(group) == "gloo"
         self._overlap = dev.type == "cuda" and not self._gloo
@@ -173,6 +174,13 @@ class ShardedSpinTorqueVecEnv:
             torch.cuda.current_stream(self.device).wait_event(self._done[k])
         return global_views(self._glob[k]) if unpack else self._glob[k]
 
+    def gather_again(self) -> None:
+        """Marks the records of the last step as not yet gathered, so that gather_begin() exchanges them once more
+        (measuring the collective by itself)."""
+        if self._last is None:
+            raise RuntimeError("nothing has been stepped yet")
+        self._filled = self._last
+
     @property
     def gather_in_flight(self) -> bool:
         """A gather_begin() is waiting for its gather_end()."""
@@ -200,7 +208,7 @@ class ShardedSpinTorqueVecEnv:
         # reset() fills the env's own record array (obs fields; reward/flags zeroed): hand it to the exchange
         k = self._next_slot()
         self._mine(k).copy_(self.local.backend.packed)
-        self._filled = k
+        self._filled = self._last = k
         return self._gather()[0], info
 
     def step(self, actions, gather: bool = True, actions_are_local: bool = False, actions_soa: bool = False):
@@ -212,7 +220,7 @@ class ShardedSpinTorqueVecEnv:
             a = a[:, self.lo:self.hi] if actions_soa else a[self.lo:self.hi]
         k = self._next_slot()
         out = self.local.step(a, actions_soa=actions_soa, out=self._mine(k))
-        self._filled = k
+        self._filled = self._last = k
         if not gather:
             return out
         obs, reward, term, trunc = self._gather()

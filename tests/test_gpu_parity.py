@@ -523,13 +523,14 @@ def test_harness_parity_single_env_rate_and_health(stg):
     print("single-env steps/s", r["steps_per_second"], " vector env-steps/s", v["env_steps_per_second"])
 
 
-def test_step_is_hip_graph_capturable(stg):
+@pytest.mark.parametrize("layout", ["soa", "records"])
+def test_step_is_hip_graph_capturable(stg, layout):
     """stg_step enqueues only kernels on the caller's stream (no allocation, no synchronisation), so a caller can
     capture plan + step into a hipGraph and replay it; the replay gives the same bits as eager launches."""
     from spin_torque_gym_amd.backend import EnvConfig, HipBackend
     n = 8192
     table = [_flat(stg, stt_default_params(volume=8.75e-11))]
-    cfg = EnvConfig(solver="rk4", include_thermal_fluctuations=True, seed=3, lane_sort=True)
+    cfg = EnvConfig(solver="rk4", include_thermal_fluctuations=True, seed=3, lane_sort=True, out_layout=layout)
     rng = np.random.default_rng(0)
     acts = torch.tensor(_uniform_actions(2e6, 1e-10, 3e-10)(rng, n, 0).T.copy(), device="cuda")
     res = []
