@@ -19,7 +19,8 @@ form; the point-to-point exchange always works that way.)
 `gather_algo`: "all_gather" (default) = `all_gather_into_tensor`, RCCL picks the algorithm; "p2p" = one grouped batch of
 7 sends + 7 receives per rank (`batch_isend_irecv`), every peer's slice over its own xGMI link at once -- the one-shot
 alternative to a ring (ring = 7 hops per link-time, direct = 1), for steps short enough that the
-collective no longer hides under the kernel.
+collective no longer hides under the kernel; it is also what ragged shards (num_envs % world != 0) use, since it does not
+need equal contributions.
 
 Actions go the other way: every rank slices its shard out of the global action tensor (a learner that is itself
 data-parallel over the same ranks passes local actions and skips the gather: ``gather=False``).
@@ -63,8 +64,10 @@ class ShardedSpinTorqueVecEnv:
         self.num_envs = int(num_envs)
         self.lo, self.hi = shard_range(self.num_envs, self.world, self.rank)
         self.n_local = self.hi - self.lo
-        if self.num_envs % self.world:
-            raise ValueError("num_envs must be divisible by the number of ranks (equal shards keep the gather a plain all-gather)")
+        self._spans = [shard_range(self.num_envs, self.world, r) for r in range(self.world)]
+        if self.num_envs % self.world and gather_algo == "all_gather":
+            # ragged shards: an all-gather needs equal contributions; the point-to-point exchange does not care
+            gather_algo = self.gather_algo = "p2p"
         if device_index is None:
             device_index = self.rank % max(torch.cuda.device_count(), 1)
         if class_index is not None:
@@ -106,12 +109,11 @@ class ShardedSpinTorqueVecEnv:
             host = torch.empty(g.shape, dtype=torch.uint8)
             if self.gather_algo == "p2p" and self.world > 1:
                 src = mine.cpu()
-                n = self.n_local
                 ops = []
-                for peer in range(self.world):
+                for peer, (plo, phi) in enumerate(self._spans):
                     if peer != self.rank:
                         ops.append(dist.P2POp(dist.isend, src, peer, group=self.group))
-                        ops.append(dist.P2POp(dist.irecv, host[peer * n:(peer + 1) * n], peer, group=self.group))
+                        ops.append(dist.P2POp(dist.irecv, host[plo:phi], peer, group=self.group))
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
                 host[self.lo:self.hi] = src
@@ -120,12 +122,11 @@ class ShardedSpinTorqueVecEnv:
             g.copy_(host)
             return
         if self.gather_algo == "p2p" and self.world > 1:
-            n = self.n_local
             ops = []
-            for peer in range(self.world):
+            for peer, (plo, phi) in enumerate(self._spans):
                 if peer != self.rank:
                     ops.append(dist.P2POp(dist.isend, mine, peer, group=self.group))
-                    ops.append(dist.P2POp(dist.irecv, g[peer * n:(peer + 1) * n], peer, group=self.group))
+                    ops.append(dist.P2POp(dist.irecv, g[plo:phi], peer, group=self.group))
             for w in dist.batch_isend_irecv(ops):
                 w.wait()            # (stream-ordered on NCCL/RCCL: does not block the host)
             return
@@ -237,9 +238,19 @@ class ShardedSpinTorqueVecEnv:
             a = torch.as_tensor(actions).to(device=dev, dtype=dtype)
             if tuple(a.shape) != (self.num_envs, 2):
                 raise ValueError(f"expected actions of shape ({self.num_envs}, 2), got {tuple(a.shape)}")
-            chunks = [c.contiguous() for c in a.split(self.n_local)]
+            chunks = [a[plo:phi].contiguous() for plo, phi in self._spans]
         gsrc = src if self.group is None else dist.get_global_rank(self.group, src)
-        dist.scatter(local, chunks, src=gsrc, group=self.group)
+        if self.num_envs % self.world == 0:
+            dist.scatter(local, chunks, src=gsrc, group=self.group)
+            return local
+        # ragged shards: one send per peer (scatter needs equal chunks)
+        if self.rank == src:
+            ops = [dist.P2POp(dist.isend, chunks[peer], peer, group=self.group) for peer in range(self.world) if peer != src]
+            local.copy_(chunks[src])
+        else:
+            ops = [dist.P2POp(dist.irecv, local, src, group=self.group)]
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
         return local
 
     def get_performance_stats(self):

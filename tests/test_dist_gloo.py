@@ -77,6 +77,16 @@ def _worker(rank, world, port, n, steps, q):
         assert all(torch.equal(x, y) for x, y in zip(out4, rec[k + 1]))
     st = env.get_performance_stats()["profiler"]
     assert st["gather_begin_count"] == steps + 1 and st["step_count"] == steps
+    # ragged shards (num_envs not divisible by the ranks): the exchange switches to point-to-point, results unchanged
+    nr = n - 1
+    env5 = ShardedSpinTorqueVecEnv(nr, **kw)
+    assert env5.gather_algo == "p2p" and (env5.hi - env5.lo) in (nr // world, nr // world + 1)
+    o5, _ = env5.reset(options={"initial_state": m0[:nr], "target_state": tgt[:nr]})
+    assert torch.equal(o5, rec[0][:nr])
+    for k in range(steps):
+        loc = env5.scatter_actions(torch.from_numpy(acts[k][:nr]) if rank == 0 else None, src=0)
+        out5 = env5.step(loc, actions_are_local=True)[:4]
+        assert all(torch.equal(x, y[:nr]) for x, y in zip(out5, rec[k + 1]))
     if rank == 0:
         q.put(rec)
     dist.barrier()
