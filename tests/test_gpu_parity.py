@@ -1282,3 +1282,31 @@ def test_results_do_not_depend_on_wavefront_composition(stg, solver):
                 ref = cur
             else:
                 assert torch.equal(ref, cur), (solver, noise, rep, int((ref != cur).any(dim=0).sum()))
+
+
+@pytest.mark.parametrize("snake,walk", [("1", None), ("1", "2"), ("0", "3"), (None, "1")])
+def test_schedule_knobs_keep_the_slot_map_a_bijection(stg, monkeypatch, snake, walk):
+    """The experiment knobs of the sorted schedule (STG_SNAKE: boustrophedon rounds forced on/off; STG_WALK_TILES: tiles an
+    XCD group walks together) only permute which wavefront integrates which 64 slots: for every setting and ragged launch
+    size each env is stepped exactly once, with the bits of the identity schedule."""
+    for key, val in (("STG_SNAKE", snake), ("STG_WALK_TILES", walk)):
+        if val is None:
+            monkeypatch.delenv(key, raising=False)
+        else:
+            monkeypatch.setenv(key, val)
+    for n in (100000, 131072 + 8192, 300000, 589824 + 4096 * 3 + 5):
+        rng = np.random.default_rng(n)
+        acts = torch.from_numpy(_uniform_actions(2e6, 1e-10, 2.5e-10)(rng, n, 0))
+        outs = []
+        for ls in (False, True):
+            env = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=False,
+                                       solver="rk4", seed=3, lane_sort=ls)
+            env.reset(seed=7)
+            o, r, te, tr, info = env.step(acts)
+            st = env.get_state()
+            assert env.backend.counters()["env_steps"] == n, (n, ls)
+            outs.append((o.clone(), info["reward_f64"].clone(), st["m"].clone(), st["step_count"].clone()))
+            env.close()
+        for x, y in zip(*outs):
+            assert torch.equal(x, y), (n, snake, walk)
+        assert bool((outs[0][3] == 1).all())
