@@ -172,6 +172,20 @@ class SpinTorqueVecEnv:
         self.single_observation_space = _box(-np.inf, np.inf, shape=(12,), dtype=np.float32)
         self._needs_reset = True
 
+    # batched spaces of gymnasium.vector.VectorEnv, built on first use (N x 2 / N x 12 bounds)
+    @property
+    def action_space(self):
+        if getattr(self, "_action_space", None) is None:
+            lo, hi = self.single_action_space.low, self.single_action_space.high
+            self._action_space = _box(np.tile(lo, (self.num_envs, 1)), np.tile(hi, (self.num_envs, 1)), dtype=np.float32)
+        return self._action_space
+
+    @property
+    def observation_space(self):
+        if getattr(self, "_observation_space", None) is None:
+            self._observation_space = _box(-np.inf, np.inf, shape=(self.num_envs, 12), dtype=np.float32)
+        return self._observation_space
+
     def _make_backend(self):
         """One context for (num_envs, cfg, env_id0) with this env's device parameters installed."""
         b = self._backend_factory(self.num_envs, self.cfg, self._device_index, self.env_id0)

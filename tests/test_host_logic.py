@@ -396,3 +396,15 @@ def test_performance_stats_timer_table(stg):
     assert p["env_steps"] == 3 and p["solver_work_units"] == 300 and p["noop_steps"] == 0
     assert st["solver"]["solve_count"] == 3 and st["solver"]["avg_solve_time"] > 0
     assert st["health"]["performance_metrics"]["total_steps"] == 3
+
+
+def test_vector_env_spaces(stg):
+    """gymnasium.vector.VectorEnv surface: num_envs, single_* and batched spaces."""
+    env = stg.SpinTorqueVecEnv(5, include_thermal_fluctuations=False, backend=OracleBackend)
+    assert env.num_envs == 5 and env.single_action_space.shape == (2,) and env.single_observation_space.shape == (12,)
+    assert env.action_space.shape == (5, 2) and env.observation_space.shape == (5, 12)
+    a = env.action_space.sample()
+    assert a.shape == (5, 2) and a.dtype == np.float32 and np.all(np.abs(a[:, 0]) <= 2e6) and np.all((a[:, 1] >= 0) & (a[:, 1] <= 5e-9))
+    obs, _ = env.reset(seed=0)
+    obs, r, te, tr, info = env.step(torch.from_numpy(a))
+    assert tuple(obs.shape) == (5, 12) and tuple(r.shape) == (5,) and te.dtype == torch.bool
