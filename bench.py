@@ -516,8 +516,8 @@ def pmc_for_run(args, argv, live=True):
 
 
 def traffic_bytes(c):
-    """HBM bytes per launch: FETCH_SIZE x 2 (gfx950: 128-B read requests tallied at 64 B; calibrated for this kernel's
-    4/8-B-per-lane loads in profiles/r01f_hbm_counter_calibration.txt) + WRITE_SIZE (exact), both reported in KB."""
+    """HBM bytes per launch: FETCH_SIZE x 2 (gfx950: 128-B read requests tallied at 64 B -- MI355X_MICROARCH.md for 16-B-per-lane
+    loads, profiles/r01f_hbm_counter_calibration.txt for 4/8-B-per-lane loads) + WRITE_SIZE (exact), both reported in KB."""
     if not c or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
         return None
     return int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
