@@ -448,6 +448,12 @@ def parse_pmc_csv(outdir, manifest):
     return out
 
 
+def workload_key(args):
+    """What the rows of a counter table depend on besides the library build."""
+    return {"envs_per_gpu": args.envs_per_gpu, "solver": args.solver, "thermal": int(bool(args.thermal)), "also": int(bool(args.also)),
+            "lane_sort": args.lane_sort, "wave_spec": args.wave_spec}
+
+
 def collect_pmc_live(argv):
     """Three rocprofv3 passes over `python3 bench.py --pmc-child ...`; returns ({row: {counter: value}}, note)."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
@@ -501,7 +507,7 @@ def pmc_for_run(args, argv, live=True):
         if tab is not None:
             if args.pmc_dump:
                 with open(args.pmc_dump, "w") as f:
-                    json.dump({"library_sha256": sha, "steps": args.steps, "warmup": args.warmup, "source": note,
+                    json.dump({"library_sha256": sha, "steps": args.steps, "warmup": args.warmup, "workload": workload_key(args), "source": note,
                                "units": "mean per timed launch; FETCH_SIZE / WRITE_SIZE in KB (uncorrected)", "rows": tab}, f, indent=1)
             return tab, note
     else:
@@ -512,7 +518,10 @@ def pmc_for_run(args, argv, live=True):
         return None, f"{note}; no committed table"
     if committed.get("library_sha256") != sha:
         return None, f"{note}; the committed table was measured on another library build"
-    return committed["rows"], f"{note}; committed table profiles/r02_pmc_rows.json (same library sha256)"
+    if committed.get("workload") != workload_key(args):
+        return None, f"{note}; the committed table was measured on other workload arguments"
+    return committed["rows"], (f"{note}; committed table profiles/r02_pmc_rows.json (same library sha256, same workload arguments, "
+                               f"measured with --steps {committed.get('steps')})")
 
 
 def traffic_bytes(c):
