@@ -126,6 +126,19 @@ def volume_for(solver):
     return 9.7e-6 if solver == "rk45" else 8.75e-11
 
 
+def cgroup_cpu_stat():
+    """CPU-bandwidth statistics of this container (cgroup v2 cpu.stat, v1 fallback): nr_periods, nr_throttled, throttled_usec."""
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            d = {k: int(v) for k, v in (ln.split() for ln in open(path).read().splitlines())}
+            if "throttled_time" in d:                   # v1 reports nanoseconds
+                d["throttled_usec"] = d["throttled_time"] // 1000
+            return d
+        except (OSError, ValueError):
+            continue
+    return {}
+
+
 class Marker:
     """PMC child passes only: one launch of a kernel nothing else uses, between rows, so that the dispatches of the
     counter CSV can be attributed to rows without counting on launch counts."""
@@ -194,9 +207,24 @@ def run_config(n_local, solver, thermal, steps, warmup, rank, world, device_inde
         env.gather_end()
     torch.cuda.synchronize(dev)
 
+    gc_log = []          # (generation, start offset in s from the block's t0, duration in s) of every collector pass
+
     def timed_block(gather=True):
         """EXACTLY `steps` steps between barrier + synchronize on both sides; also the same span seen from the device."""
         backend.counters(reset=True)
+        debug = bool(os.environ.get("STG_BENCH_DEBUG"))
+        host_t = []
+        gc_t = [0.0]
+
+        def _gc_cb(phase, info):
+            if phase == "start":
+                gc_t[0] = time.perf_counter()
+            else:
+                gc_log.append((info["generation"], gc_t[0], time.perf_counter() - gc_t[0]))
+        if debug:
+            import gc
+            gc.callbacks.append(_gc_cb)
+        cg0 = cgroup_cpu_stat()
         starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
         ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
         fin = torch.cuda.Event(enable_timing=True)
@@ -205,6 +233,8 @@ def run_config(n_local, solver, thermal, steps, warmup, rank, world, device_inde
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for k in range(steps):
+            if debug:
+                host_t.append(time.perf_counter())
             starts[k].record()
             if world == 1:
                 backend.step(acts[warmup + k], autoreset=True)       # the step kernel, on torch's current stream
@@ -219,10 +249,19 @@ def run_config(n_local, solver, thermal, steps, warmup, rank, world, device_inde
         if world > 1 and gather:
             env.gather_end()                                         # (typed global views: obs [N,12], reward, flags)
         fin.record()
+        t_enq = time.perf_counter()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         t1 = time.perf_counter()
+        if debug:
+            import gc
+            gc.callbacks.remove(_gc_cb)
+            cg1 = cgroup_cpu_stat()
+            print("debug host: enqueue of %d steps %.3f ms, synchronize %.3f ms; gc passes in block: %s; cgroup cpu.stat delta over the block: %s" % (
+                steps, (t_enq - t0) * 1e3, (t1 - t_enq) * 1e3,
+                [(g, round((a - t0) * 1e3, 3), round(d * 1e3, 3)) for g, a, d in gc_log if a >= t0],
+                {k: cg1.get(k, 0) - cg0.get(k, 0) for k in ("nr_periods", "nr_throttled", "throttled_usec")}), file=sys.stderr, flush=True)
         return t1 - t0, [s.elapsed_time(e) for s, e in zip(starts, ends)], starts[0].elapsed_time(fin) * 1e-3
 
     # The GPU boxes of this pool show a sporadic ~80 ms hiccup (the device finishes -- its own event timestamps are
@@ -661,6 +700,17 @@ def main():
     if args.pmc_child:
         pmc_child(args)
         return
+    if os.environ.get("STG_BENCH_DEBUG"):
+        import gc
+        _g0 = [0.0]
+
+        def _gc_all(phase, info):        # every collector pass of this process, with its duration
+            if phase == "start":
+                _g0[0] = time.perf_counter()
+            elif info["generation"] >= 1:
+                print("debug gc: generation %d pass took %.3f ms (collected %d) at t=%.3f s" % (
+                    info["generation"], (time.perf_counter() - _g0[0]) * 1e3, info["collected"], time.perf_counter()), file=sys.stderr, flush=True)
+        gc.callbacks.append(_gc_all)
     # hardware counters first: the child passes must be started before this process initialises the GPU
     pmc_tab, pmc_src = pmc_for_run(args, child_argv(args), live=(world == 1)) if rank == 0 else (None, "rank > 0")
     import torch.distributed as dist

@@ -185,7 +185,9 @@ int stg_set_params_per_env(stg_ctx* ctx, const double* soa_params, const uint8_t
  * init_m / target [dev] double[3][N]: options['initial_state'] / options['target_state'] (normalised by the kernel as
  * device.validate_magnetization does); NULL: drawn on the device (normal(0,1,3) normalised; uniform choice among
  * cfg.targets) from Philox(seed, env_id, episode).  obs_out [dev] float[12][N] (cfg.out_layout = STG_OUT_RECORDS: the
- * record array, whose obs fields are written and whose reward/flag fields are zeroed for the reset envs) may be NULL. */
+ * record array, 8-byte aligned: the obs fields of every env are written -- a masked call reports the current observation of
+ * the envs it leaves alone --, the reward/flag fields are zeroed for the reset envs and left untouched for the others)
+ * may be NULL. */
 int stg_reset(stg_ctx* ctx, const uint8_t* mask, const double* init_m, const double* target,
               uint64_t seed, float* obs_out, void* stream);
 
@@ -205,7 +207,8 @@ int stg_step(stg_ctx* ctx, const void* actions, int32_t act_f64, float* obs, flo
  * reports that step's reward / terminated / truncated, is then reset on the device (as stg_reset with NULL
  * init_m/target, Philox key cfg.seed) and its obs row holds the NEW episode's first observation; final_obs
  * (float[K or 1][12][N] -- float[K or 1][N][12] with STG_OUT_RECORDS --, may be NULL) receives the terminal observation of
- * such envs (entries of other envs untouched). */
+ * such envs (entries of other envs untouched).  With STG_OUT_RECORDS the record array and final_obs must be 8-byte
+ * aligned (the kernel stores float pairs); a misaligned pointer is rejected with STG_E_INVALID. */
 int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64, int32_t out_every, int32_t autoreset,
                   float* obs, float* final_obs, float* reward, double* reward_f64, double* energy, uint8_t* terminated,
                   uint8_t* truncated, uint8_t* status, void* stream);

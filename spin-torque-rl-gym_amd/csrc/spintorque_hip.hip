@@ -73,7 +73,9 @@ __global__ void __launch_bounds__(64) stg_reset_kernel(const ResetArgs a) {
     load_state(a.s, i, m0, t0, etot0, step0, rng0, done0);
     if (a.mask && !a.mask[i]) {
         if (a.obs) {   // unchanged env: report its current observation (last action unknown -> 0, as after reset)
-            if (a.records) write_record(a.obs, i, m0, t0, row, a.c, step0, etot0, 0.0, 0.0, 0.0f, 0u);
+            // (records: only the observation fields -- reward and flags of an env that is not reset are its last step's,
+            // which the caller may still be reading: `reward`/`terminated` of SpinTorqueVecEnv.step are views of this array)
+            if (a.records) write_record_obs(a.obs, i, m0, t0, row, a.c, step0, etot0, 0.0, 0.0);
             else write_obs(a.obs, N, i, m0, t0, row, a.c, step0, etot0, 0.0, 0.0);
         }
         return;
@@ -480,6 +482,8 @@ int stg_reset(stg_ctx* ctx, const uint8_t* mask, const double* init_m, const dou
               float* obs_out, void* stream) {
     if (!ctx) return fail(STG_E_INVALID, "ctx is NULL");
     if (!ctx->have_params) return fail(STG_E_STATE, "stg_set_params must be called before stg_reset");
+    if (ctx->cfg.out_layout == STG_OUT_RECORDS && ((uintptr_t)obs_out & 7u))
+        return fail(STG_E_INVALID, "the record array must be 8-byte aligned");
     HIP_TRY(hipSetDevice(ctx->device));
     ResetArgs a{};
     a.s = ctx->s; a.c = cfg_view(ctx->cfg); a.N = ctx->N; a.env_id0 = ctx->env_id0;
@@ -502,6 +506,7 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
     if (!actions || !obs) return fail(STG_E_INVALID, "actions/obs must not be NULL");
     if (!records && (!reward || !terminated || !truncated)) return fail(STG_E_INVALID, "reward/terminated/truncated must not be NULL (cfg.out_layout = STG_OUT_SOA)");
     if (records && ((uintptr_t)obs & 7u)) return fail(STG_E_INVALID, "the record array must be 8-byte aligned");
+    if (records && ((uintptr_t)final_obs & 7u)) return fail(STG_E_INVALID, "final_obs must be 8-byte aligned (cfg.out_layout = STG_OUT_RECORDS)");
     HIP_TRY(hipSetDevice(ctx->device));
     StepArgs a{};
     a.s = ctx->s; a.c = cfg_view(ctx->cfg); a.N = ctx->N; a.env_id0 = ctx->env_id0;

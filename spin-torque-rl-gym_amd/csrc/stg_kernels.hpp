@@ -267,6 +267,17 @@ __device__ __forceinline__ void write_record(void* base, int64_t i, const V3& m,
     rec[6] = make_float2(reward, __uint_as_float(flags));
 }
 
+// ... or only the 48 observation bytes of env i's record (a masked stg_reset reporting an env it does NOT reset: the
+// reward / flag fields of that record still belong to the env's last step and stay as they are)
+__device__ __forceinline__ void write_record_obs(void* base, int64_t i, const V3& m, const V3& tgt, const double* row,
+                                                 const CfgView& c, int32_t step, double etot, double J, double T) {
+    float o[12];
+    make_obs(o, m, tgt, row, c, step, etot, J, T);
+    float2* rec = (float2*)((char*)base + i * STG_RECORD_BYTES);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) rec[k] = make_float2(o[2 * k], o[2 * k + 1]);
+}
+
 constexpr int COUNTER_STRIPES = 1024;     // copies of the on-device counters (one 64-byte line each)
 constexpr int COUNTER_STRIDE = 8;         // u64 per stripe
 

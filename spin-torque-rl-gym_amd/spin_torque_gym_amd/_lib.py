@@ -20,6 +20,7 @@ DEV_TYPES = {"stt_mram": 0, "sot_mram": 1, "vcma_mram": 2}
 OUT_LAYOUTS = {"soa": 0, "records": 1}
 RECORD_BYTES = 56        # STG_RECORD_BYTES
 STATUS_OK, STATUS_NOOP, STATUS_RESET, STATUS_INACTIVE = 0, 1, 2, 3
+STG_OK, STG_E_INVALID, STG_E_HIP, STG_E_NOMEM, STG_E_STATE = 0, -1, -2, -3, -4
 
 
 class StgConfig(C.Structure):

@@ -41,6 +41,10 @@ class EnvConfig:
     correlation_time: float = 1e-12           # ThermalFluctuations.correlation_time, for noise_model='ou'
     out_layout: str = "soa"                   # 'soa': obs [12,N] + reward/terminated/truncated arrays; 'records': one
                                               # [N,56]-byte record array (what the multi-GPU gather moves, copy-free)
+    diagnostics: bool = False                 # also write the step's fp64 reward, per-step energy, status bytes and -- with
+                                              # auto-reset -- terminal observations into separate arrays (the C-ABI's optional
+                                              # outputs).  Off: those pointers are NULL, a step writes the RL-facing outputs only
+                                              # (the status still rides in byte 54 of each record with out_layout='records')
 
     def to_abi(self) -> "_lib.StgConfig":
         if self.solver not in _lib.SOLVERS:
@@ -144,9 +148,16 @@ class HipBackend:
         #  and `obs` is a strided [12,N] view (its .t() is Gym's [N,12]).
         self.records_layout = cfg.out_layout == "records"
         self.packed, self.obs, self.reward, self.terminated, self.truncated = alloc_step_outputs(n, dev, cfg.out_layout)
-        self.reward64 = torch.empty(n, dtype=torch.float64, device=dev)
-        self.energy = torch.empty(n, dtype=torch.float64, device=dev)
-        self.status = torch.empty(n, dtype=torch.uint8, device=dev)
+        self.diagnostics = bool(getattr(cfg, "diagnostics", False))
+        if self.diagnostics:
+            self.reward64 = torch.empty(n, dtype=torch.float64, device=dev)
+            self.energy = torch.empty(n, dtype=torch.float64, device=dev)
+            self.status = torch.empty(n, dtype=torch.uint8, device=dev)
+        else:
+            # the hot path writes nothing but the RL-facing outputs; in the records layout the status byte of each record
+            # is still there (a view), in the SoA layout there is no status without diagnostics
+            self.reward64 = self.energy = None
+            self.status = record_views(self.packed)[4] if self.records_layout else None
         self.final_obs = None                 # [12,N] (a view of [N,12] in the records layout), allocated on the first auto-resetting step
         self._final_buf = None
 
@@ -223,7 +234,7 @@ class HipBackend:
         a = torch.as_tensor(actions)
         f64 = a.dtype == torch.float64
         a = self._dev(a, torch.float64 if f64 else torch.float32, (2, self.n))
-        if autoreset and self.final_obs is None:
+        if autoreset and self.diagnostics and self.final_obs is None:
             if self.records_layout:           # env-major like the records: one 48-byte block per env
                 self._final_buf = torch.zeros((self.n, 12), dtype=torch.float32, device=self.device)
                 self.final_obs = self._final_buf.t()
@@ -233,18 +244,19 @@ class HipBackend:
             rec = self.packed if out is None else out
             if rec.dtype != torch.uint8 or tuple(rec.shape) != (self.n, RECORD_BYTES) or not rec.is_contiguous() or rec.device != self.device:
                 raise ValueError(f"out must be a contiguous uint8 [{self.n}, {RECORD_BYTES}] tensor on {self.device}")
+            diag = self.diagnostics
             _lib.check(self.lib.stg_step_many(self._ctx, 1, _ptr(a), int(f64), 1, int(bool(autoreset)), _ptr(rec),
-                                              _ptr(self._final_buf) if autoreset else None, None, _ptr(self.reward64),
-                                              _ptr(self.energy), None, None, _ptr(self.status), self._stream()))
+                                              _ptr(self._final_buf) if (autoreset and diag) else None, None, _ptr(self.reward64),
+                                              _ptr(self.energy), None, None, _ptr(self.status) if diag else None, self._stream()))
             self._keep = (a,)
             if out is None:
                 return self.obs, self.reward, self.reward64, self.terminated, self.truncated, self.status
-            obs, reward, term, trunc, _ = record_views(rec)
-            return obs.t(), reward, self.reward64, term, trunc, self.status
+            obs, reward, term, trunc, st = record_views(rec)
+            return obs.t(), reward, self.reward64, term, trunc, (self.status if diag else st)
         if out is not None:
             raise ValueError("out= needs out_layout='records'")
         _lib.check(self.lib.stg_step_many(self._ctx, 1, _ptr(a), int(f64), 1, int(bool(autoreset)), _ptr(self.obs),
-                                          _ptr(self.final_obs) if autoreset else None,
+                                          _ptr(self.final_obs) if (autoreset and self.diagnostics) else None,
                                           _ptr(self.reward), _ptr(self.reward64), _ptr(self.energy),
                                           _ptr(self.terminated), _ptr(self.truncated), _ptr(self.status),
                                           self._stream()))
@@ -269,12 +281,13 @@ class HipBackend:
             term = torch.empty((ko, n), dtype=torch.uint8, device=dev)
             trunc = torch.empty((ko, n), dtype=torch.uint8, device=dev)
             out_ptr = obs
-        reward64 = torch.empty((ko, n), dtype=torch.float64, device=dev)
-        status = torch.empty((ko, n), dtype=torch.uint8, device=dev)
-        self.energy_many = torch.empty((ko, n), dtype=torch.float64, device=dev)
+        diag = self.diagnostics
+        reward64 = torch.empty((ko, n), dtype=torch.float64, device=dev) if diag else None
+        status = torch.empty((ko, n), dtype=torch.uint8, device=dev) if diag else (record_views(rec)[4] if self.records_layout else None)
+        self.energy_many = torch.empty((ko, n), dtype=torch.float64, device=dev) if diag else None
         fbuf = None
         self.final_obs_many = None
-        if autoreset:
+        if autoreset and diag:
             if self.records_layout:
                 fbuf = torch.zeros((ko, n, 12), dtype=torch.float32, device=dev)
                 self.final_obs_many = fbuf.transpose(1, 2)
@@ -283,7 +296,7 @@ class HipBackend:
         _lib.check(self.lib.stg_step_many(self._ctx, K, _ptr(a), int(f64), int(bool(out_every)), int(bool(autoreset)),
                                           _ptr(out_ptr), _ptr(fbuf), None if self.records_layout else _ptr(reward),
                                           _ptr(reward64), _ptr(self.energy_many), None if self.records_layout else _ptr(term),
-                                          None if self.records_layout else _ptr(trunc), _ptr(status), self._stream()))
+                                          None if self.records_layout else _ptr(trunc), _ptr(status) if diag else None, self._stream()))
         self._keep = (a,)
         return obs, reward, reward64, term, trunc, status
 

@@ -118,6 +118,9 @@ class SpinTorqueVecEnv:
     row stride 14 floats); ``out_layout='soa'`` keeps four separate arrays with a component-major [12,N] obs buffer, of which
     ``obs`` is the transposed view.  No copies either way.  Actions are accepted as [N,2] (Gym convention) or, with
     ``actions_soa=True``, as the kernel's [2,N].
+    ``diagnostics=True`` additionally fills ``info['reward_f64']`` (the reward before rounding to fp32), ``info['energy']``
+    (the reference's info['energy_consumed'], spin_torque_env.py:474-480) and, with ``autoreset``, ``info['final_obs']``;
+    by default a step writes the RL-facing outputs only (``info['status']`` is then the records' status byte).
     """
 
     def __init__(self, num_envs: int, device_type: Union[str, Sequence[str]] = "stt_mram",
@@ -130,7 +133,7 @@ class SpinTorqueVecEnv:
                  max_attempts: int = 200_000, lane_sort: Optional[bool] = None, wave_spec: Optional[bool] = None, torque_model: str = "reference",
                  noise_model: str = "white", correlation_time: float = 1e-12,
                  per_env_params: Optional[Dict[str, Any]] = None, out_layout: str = "records",
-                 backend=None):
+                 diagnostics: bool = False, backend=None):
         self.num_envs = int(num_envs)
         factory = DeviceFactory()
         types = [device_type] if isinstance(device_type, str) else list(device_type)
@@ -157,8 +160,9 @@ class SpinTorqueVecEnv:
                              seed=int(self._rng.integers(0, 2**63 - 1)) if seed is None else int(seed),
                              max_attempts=max_attempts, skip_done=skip_done, lane_sort=lane_sort, wave_spec=wave_spec,
                              torque_model=torque_model, noise_model=noise_model, correlation_time=correlation_time,
-                             out_layout=out_layout)
+                             out_layout=out_layout, diagnostics=bool(diagnostics))
         self.autoreset = bool(autoreset)
+        self.diagnostics = bool(diagnostics)
         # `backend` is a test seam: a class/callable with HipBackend's constructor signature (tests inject the CPU
         # oracle for the gloo runs and as the comparator); the product default is the HIP library, nothing else.
         self._backend_factory = HipBackend if backend is None else backend
@@ -231,11 +235,16 @@ class SpinTorqueVecEnv:
         else:
             obs, rew, rew64, term, trunc, status = self.backend.step(a, autoreset=self.autoreset, out=out)
         self.profiler.add("step", time.perf_counter() - t0)
-        info = {"status": status, "reward_f64": rew64, "energy": self.backend.energy}
-        if self.autoreset:
-            # same-step auto-reset: rows of `obs` whose episode just ended already hold the new episode's first
-            # observation; their terminal observation is in info["final_obs"] (valid where terminated | truncated)
-            info["final_obs"] = self.backend.final_obs.t()
+        # diagnostics=False (default): the launch writes the RL-facing outputs only; `status` is then the status byte of the
+        # records (a view; absent in the SoA layout).  diagnostics=True adds the fp64 reward, the step's Joule energy and --
+        # with auto-reset -- the terminal observations (the reference's info['energy_consumed'] etc. at N = 1).
+        info = {} if status is None else {"status": status}
+        if self.diagnostics:
+            info.update(reward_f64=rew64, energy=self.backend.energy)
+            if self.autoreset:
+                # same-step auto-reset: rows of `obs` whose episode just ended already hold the new episode's first
+                # observation; their terminal observation is in info["final_obs"] (valid where terminated | truncated)
+                info["final_obs"] = self.backend.final_obs.t()
         return obs.t(), rew, term.bool(), trunc.bool(), info
 
     def step_many(self, actions, out_every: bool = True, actions_soa: bool = False):
@@ -246,8 +255,10 @@ class SpinTorqueVecEnv:
         t0 = time.perf_counter()
         obs, rew, rew64, term, trunc, status = self.backend.step_many(a, out_every=out_every, autoreset=self.autoreset)
         self.profiler.add("step_many", time.perf_counter() - t0)
-        return obs.transpose(1, 2), rew, term.bool(), trunc.bool(), {"status": status, "reward_f64": rew64,
-                                                                      "energy": self.backend.energy_many}
+        info = {} if status is None else {"status": status}
+        if self.diagnostics:
+            info.update(reward_f64=rew64, energy=self.backend.energy_many)
+        return obs.transpose(1, 2), rew, term.bool(), trunc.bool(), info
 
     def _soa3(self, v):
         if v is None:
@@ -345,7 +356,7 @@ class SpinTorqueEnv(_EnvBase):
         self._vec = SpinTorqueVecEnv(1, device_type, device_params, None, target_states, max_steps, max_current,
                                      max_duration, temperature, include_thermal_fluctuations, success_threshold,
                                      energy_penalty_weight, solver, seed, False, False,
-                                     device_index, 0, backend=backend)
+                                     device_index, 0, diagnostics=True, backend=backend)
         self.device = self._vec.devices[0]
         self.target_states = self._vec.target_states
         self.solver_name = solver

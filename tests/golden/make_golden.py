@@ -380,7 +380,7 @@ def G10():
     T = 2e-10
     det = run_robust(solver, m0, T, params, 0.0, thermal=False)["m"][-1]
     np.random.seed(7)
-    samples = np.array([run_robust(solver, m0, T, params, 0.0, thermal=True, temperature=300.0)["m"][-1] for _ in range(600)])
+    samples = np.array([run_robust(solver, m0, T, params, 0.0, thermal=True, temperature=300.0)["m"][-1] for _ in range(4000)])
     out.update(rk4_m0=m0, rk4_T=T, rk4_volume=1e-30, rk4_deterministic=det, rk4_samples=samples)
     print(f"    rk4 diffusion: rms deviation {np.sqrt(((samples - det) ** 2).sum(axis=1).mean()):.3e}")
     # (c) diffusion samples, LLGSSolver RK45
@@ -389,7 +389,7 @@ def G10():
     det = guarded(60, llgs.solve, m0.copy(), (0, T), params, pulse(0.0, T), zero_field, thermal_noise=False)["m"][-1]
     np.random.seed(11)
     samples, npts = [], []
-    for _ in range(200):
+    for _ in range(1000):
         r = guarded(120, llgs.solve, m0.copy(), (0, T), params, pulse(0.0, T), zero_field, thermal_noise=True, temperature=300.0)
         samples.append(r["m"][-1])
         npts.append(len(r["t"]))

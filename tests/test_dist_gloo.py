@@ -121,7 +121,7 @@ def test_two_rank_sharded_env_equals_single_process(oracle_mod):
         assert p.exitcode == 0
     # single-process run over all n envs
     m0, tgt, acts = _inputs(n, steps)
-    env = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=True,
+    env = stg.SpinTorqueVecEnv(n, diagnostics=True, device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=True,
                                seed=77, backend=OracleBackend)
     obs, _ = env.reset(options={"initial_state": m0, "target_state": tgt})
     assert torch.equal(rec[0], obs)

@@ -63,7 +63,7 @@ def _slice_starts(n):
 def _run_hip(stg, n, m0, tgt, acts, cls=None, keep=None, **kw):
     """Steps the HIP env through `acts`; returns the device tensors of every step (cloned) -- `keep` (index tensor on the
     device) restricts what is kept to those envs (the 1M-env case)."""
-    env = stg.SpinTorqueVecEnv(n, class_index=cls, **kw)
+    env = stg.SpinTorqueVecEnv(n, diagnostics=True, class_index=cls, **kw)
     env.reset(options={"initial_state": m0, "target_state": tgt})
     sel = (lambda t: t.index_select(-1, keep)) if keep is not None else (lambda t: t)
     rec = []
@@ -84,7 +84,7 @@ def _run_hip(stg, n, m0, tgt, acts, cls=None, keep=None, **kw):
 def _run_oracle_slice(stg, s0, m0, tgt, acts, cls=None, **kw):
     from helpers import OracleBackend
     sl = slice(s0, s0 + SLICE)
-    env = stg.SpinTorqueVecEnv(SLICE, class_index=None if cls is None else cls[sl], env_id0=s0, backend=OracleBackend, **kw)
+    env = stg.SpinTorqueVecEnv(SLICE, diagnostics=True, class_index=None if cls is None else cls[sl], env_id0=s0, backend=OracleBackend, **kw)
     env.reset(options={"initial_state": m0[sl], "target_state": tgt[sl]})
     rec = []
     for a in acts:
@@ -186,7 +186,7 @@ def test_cfg5_shard_rk45_thermal_131072_vs_oracle_slices(stg):
     for s0 in _slice_starts(n)[::2]:
         from helpers import OracleBackend
         sl = slice(s0, s0 + SLICE)
-        env = stg.SpinTorqueVecEnv(SLICE, env_id0=id0 + s0, backend=OracleBackend, **kw)
+        env = stg.SpinTorqueVecEnv(SLICE, diagnostics=True, env_id0=id0 + s0, backend=OracleBackend, **kw)
         env.reset(options={"initial_state": m0[sl], "target_state": tgt[sl]})
         ora = []
         for a in acts:
@@ -299,12 +299,12 @@ def test_cfg2a_1m_envs_step_many_k8_vs_steps_and_oracle(stg):
     starts = _slice_starts(n)
     keep = torch.cat([torch.arange(s, s + SLICE) for s in starts]).cuda()
 
-    e1 = stg.SpinTorqueVecEnv(n, **kw)
+    e1 = stg.SpinTorqueVecEnv(n, diagnostics=True, **kw)
     e1.reset(options={"initial_state": m0, "target_state": tgt})
     om, rm, tem, trm, im = e1.step_many(torch.from_numpy(acts), out_every=False)
     st1 = e1.get_state()
     c1 = e1.backend.counters()
-    e2 = stg.SpinTorqueVecEnv(n, **kw)
+    e2 = stg.SpinTorqueVecEnv(n, diagnostics=True, **kw)
     e2.reset(options={"initial_state": m0, "target_state": tgt})
     per_step = []
     for k in range(K):
@@ -385,7 +385,7 @@ def test_cfg3_switching_statistics_grid_independent_streams(stg):
     n = len(bins) * STAT_N
     m0 = np.array([0.05, 0.0, 1.0]); m0 /= np.linalg.norm(m0)
     par = stt_default_params(volume=1e-28)
-    env = stg.SpinTorqueVecEnv(n, device_params=par, include_thermal_fluctuations=True, solver="rk4", seed=11)
+    env = stg.SpinTorqueVecEnv(n, diagnostics=True, device_params=par, include_thermal_fluctuations=True, solver="rk4", seed=11)
     env.reset(options={"initial_state": m0, "target_state": np.array([0.0, 0.0, -1.0])})
     a = np.empty((n, 2), dtype=np.float32)
     for b, (J, T) in enumerate(bins):
@@ -423,7 +423,7 @@ def test_cfg3_switching_statistics_well_conditioned_volume(stg):
     for b, (J, T) in enumerate(bins):
         a[b * STAT_N:(b + 1) * STAT_N] = (J, T)
     for solver, vol in (("rk4", 8.75e-11), ("rk45", 9.7e-6)):
-        env = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(volume=vol), include_thermal_fluctuations=True,
+        env = stg.SpinTorqueVecEnv(n, diagnostics=True, device_params=stt_default_params(volume=vol), include_thermal_fluctuations=True,
                                    solver=solver, seed=5)
         env.reset(options={"initial_state": cap(1), "target_state": np.array([0.0, 0.0, -1.0])})
         _, _, te, tr, info = env.step(torch.from_numpy(a))

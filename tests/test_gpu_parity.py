@@ -182,7 +182,7 @@ def _run_pair(stg, n, steps, actions_fn, seed=0, **kw):
     rng = np.random.default_rng(seed)
     m0 = unit_rows(rng, n)
     tgt = np.where(rng.integers(0, 2, (n, 1)) == 0, 1.0, -1.0) * np.array([[0.0, 0.0, 1.0]])
-    envs = [stg.SpinTorqueVecEnv(n, **kw), stg.SpinTorqueVecEnv(n, backend=OracleBackend, **kw)]
+    envs = [stg.SpinTorqueVecEnv(n, diagnostics=True, **kw), stg.SpinTorqueVecEnv(n, diagnostics=True, backend=OracleBackend, **kw)]
     outs = []
     for env in envs:
         o, _ = env.reset(options={"initial_state": m0, "target_state": tgt})
@@ -358,7 +358,7 @@ def test_full_size_properties_65536(stg):
 
 def test_skip_done_and_autoreset(stg):
     n = 256
-    env = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=False,
+    env = stg.SpinTorqueVecEnv(n, diagnostics=True, device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=False,
                                max_steps=2, skip_done=True, seed=5)
     env.reset(seed=1)
     a = torch.zeros((n, 2), dtype=torch.float32); a[:, 1] = 1e-10
@@ -368,7 +368,7 @@ def test_skip_done_and_autoreset(stg):
     assert (te | tr).all() and (info["status"] == 3).all()
     assert torch.equal(env.get_state()["m"], m_before)
     env.close()
-    env = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=False,
+    env = stg.SpinTorqueVecEnv(n, diagnostics=True, device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=False,
                                max_steps=2, autoreset=True, seed=5)
     env.reset(seed=1)
     for _ in range(5):
@@ -383,8 +383,8 @@ def test_step_many_equals_repeated_step(stg):
     rng = np.random.default_rng(2)
     acts = np.stack([_uniform_actions(2e6, 1e-10, 3e-10)(rng, n, s) for s in range(K)])     # [K,N,2]
     kw = dict(device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=True, seed=8)
-    e1 = stg.SpinTorqueVecEnv(n, **kw); e1.reset(seed=3)
-    e2 = stg.SpinTorqueVecEnv(n, **kw); e2.reset(seed=3)
+    e1 = stg.SpinTorqueVecEnv(n, diagnostics=True, **kw); e1.reset(seed=3)
+    e2 = stg.SpinTorqueVecEnv(n, diagnostics=True, **kw); e2.reset(seed=3)
     obs_k = []
     for k in range(K):
         o, r, te, tr, info = e1.step(torch.from_numpy(acts[k]))
@@ -401,10 +401,10 @@ def test_state_dict_roundtrip(stg):
     n = 128
     kw = dict(device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=True, seed=8)
     a = torch.from_numpy(_uniform_actions(2e6, 1e-10, 3e-10)(np.random.default_rng(0), n, 0))
-    e1 = stg.SpinTorqueVecEnv(n, **kw); e1.reset(seed=3); e1.step(a)
+    e1 = stg.SpinTorqueVecEnv(n, diagnostics=True, **kw); e1.reset(seed=3); e1.step(a)
     sd = e1.state_dict()
     o1, r1, *_ = e1.step(a)
-    e2 = stg.SpinTorqueVecEnv(n, **kw); e2.load_state_dict(sd)
+    e2 = stg.SpinTorqueVecEnv(n, diagnostics=True, **kw); e2.load_state_dict(sd)
     o2, r2, *_ = e2.step(a)
     assert torch.equal(o1, o2) and torch.equal(r1, r2)
     e1.close(); e2.close()
@@ -453,7 +453,7 @@ def test_float64_actions_match_reference_semantics(stg):
     """A float64 action array is clamped in float64 (monitoring.py:304-313 works in the array's dtype)."""
     n = 64
     kw = dict(device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=False, seed=2)
-    e32 = stg.SpinTorqueVecEnv(n, **kw); e64 = stg.SpinTorqueVecEnv(n, **kw)
+    e32 = stg.SpinTorqueVecEnv(n, diagnostics=True, **kw); e64 = stg.SpinTorqueVecEnv(n, diagnostics=True, **kw)
     e32.reset(seed=1); e64.reset(seed=1)
     a = torch.zeros((n, 2), dtype=torch.float64); a[:, 0] = 1.5e6; a[:, 1] = 1e-12      # 1e-12 is exact only in float64
     o64, *_ = e64.step(a)
@@ -632,13 +632,13 @@ def test_kernel_variant_matrix_vs_oracle(stg, solver):
                 kw.update(include_thermal_fluctuations=thermal, solver=solver, seed=5)
                 res = []
                 for backend in (None, OracleBackend):
-                    env = stg.SpinTorqueVecEnv(n, backend=backend, **kw)
+                    env = stg.SpinTorqueVecEnv(n, diagnostics=True, backend=backend, **kw)
                     env.reset(options={"initial_state": m0, "target_state": tgt})
                     o, r, te, tr, info = env.step(torch.from_numpy(act))
                     res.append((o.cpu().numpy().copy(), info["reward_f64"].cpu().numpy().copy(), te.cpu().numpy().copy(),
                                 info["status"].cpu().numpy().copy(), env.get_state()["m"].cpu().numpy().copy()))
                     if backend is None:       # float64 actions carrying the same values take the other instantiation
-                        env2 = stg.SpinTorqueVecEnv(n, **kw)
+                        env2 = stg.SpinTorqueVecEnv(n, diagnostics=True, **kw)
                         env2.reset(options={"initial_state": m0, "target_state": tgt})
                         o64, *_ = env2.step(torch.from_numpy(act.astype(np.float64)))
                         assert torch.equal(o64, o), (solver, thermal, multi, general_axis)
@@ -682,7 +682,7 @@ def test_wave_specialised_kernels_bit_identical(stg, solver):
                 kw.update(max_attempts=150)   # ~0.13 ns worth of attempts: most lanes end as STG_STATUS_NOOP
             outs = []
             for ws in (False, True):
-                env = stg.SpinTorqueVecEnv(n, wave_spec=ws, **kw)
+                env = stg.SpinTorqueVecEnv(n, diagnostics=True, wave_spec=ws, **kw)
                 env.reset(seed=4)
                 o1, r1, te1, tr1, i1 = env.step(torch.from_numpy(acts[0]))
                 om, rm, tem, trm, im = env.step_many(torch.from_numpy(acts))
@@ -892,7 +892,7 @@ def test_pipelined_gather_overlaps_and_matches_sync(stg):
         rng = np.random.default_rng(3)
         acts = [torch.from_numpy(_uniform_actions(2e6, 1e-10, 3e-10)(rng, n, k)) for k in range(steps)]
         kw = dict(device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=True, seed=9, autoreset=True)
-        plain = stg.SpinTorqueVecEnv(n, **kw); plain.reset(seed=2)
+        plain = stg.SpinTorqueVecEnv(n, diagnostics=True, **kw); plain.reset(seed=2)
         want = []
         for a in acts:
             o, r, te, tr, _ = plain.step(a)
@@ -938,7 +938,7 @@ def test_record_output_layout_equals_soa(stg, solver, thermal):
                   autoreset=True, max_steps=2)
         outs = []
         for layout in ("soa", "records"):
-            env = stg.SpinTorqueVecEnv(n, out_layout=layout, **kw)
+            env = stg.SpinTorqueVecEnv(n, diagnostics=True, out_layout=layout, **kw)
             o0, _ = env.reset(seed=1)
             rec = [o0.clone()]
             o, r, te, tr, info = env.step(torch.from_numpy(acts[0]))
@@ -963,6 +963,109 @@ def test_record_output_layout_equals_soa(stg, solver, thermal):
             assert torch.equal(x, y), (solver, n, j)
 
 
+def test_masked_reset_keeps_reward_and_flags_of_other_envs(stg):
+    """with out_layout='records' the reward / terminated / truncated tensors step() returns are views of the
+    record array a masked reset() writes the observations into.  The usual non-autoreset loop
+    `o, r, te, tr, _ = env.step(a); env.reset(options={'mask': te | tr})` must not change r / te / tr of the envs it does not
+    reset (the reset ones read 0, as the header says); in both layouts the observation rows of the others are their current
+    observation with last_action = 0."""
+    n = 4096
+    rng = np.random.default_rng(8)
+    a = _uniform_actions(2e6, 1e-10, 3e-10)(rng, n, 0)
+    for layout in ("records", "soa"):
+        env = stg.SpinTorqueVecEnv(n, diagnostics=True, device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=False,
+                                   solver="rk4", seed=3, max_steps=2, out_layout=layout)
+        env.reset(seed=1)
+        env.step(torch.from_numpy(a))
+        o, r, te, tr, info = env.step(torch.from_numpy(a))                   # max_steps = 2: every env is truncated now
+        assert bool(tr.all()) and bool((r != 0).any())
+        r0, te0, tr0, st0 = r.clone(), te.clone(), tr.clone(), info["status"].clone()
+        o0 = o.clone()
+        mask = torch.arange(n, device=r.device) % 3 == 0
+        o1, _ = env.reset(seed=2, options={"mask": mask})
+        keep = ~mask
+        if layout == "records":
+            from spin_torque_gym_amd.backend import record_views
+            _, rr, tt, uu, ss = record_views(env.backend.packed)
+            assert torch.equal(rr[keep], r0[keep]) and torch.equal(tt[keep].bool(), te0[keep]) and torch.equal(uu[keep].bool(), tr0[keep])
+            assert torch.equal(ss[keep], st0[keep])
+            assert bool((rr[mask] == 0).all()) and not bool(tt[mask].any()) and not bool(uu[mask].any())
+            # the tensors handed out by step() are those views
+            assert torch.equal(r[keep], r0[keep]) and torch.equal(tr[keep], tr0[keep])
+        # observation of an env that was not reset: unchanged but for the last-action fields (reported as 0)
+        assert torch.equal(o1[keep][:, :10], o0[keep][:, :10]) and bool((o1[keep][:, 10:] == 0).all())
+        assert bool((o1[mask][:, 8] == 1.0).all())                           # fresh episodes: all steps remaining
+        env.close()
+
+
+@pytest.mark.parametrize("layout", ["records", "soa"])
+def test_diagnostics_off_is_the_same_step_with_fewer_outputs(stg, layout):
+    """by default (diagnostics=False) a step passes NULL for the C-ABI's optional outputs (fp64 reward,
+    energy, status array, final_obs) and writes the RL-facing outputs only; obs / reward / flags / state are bit-identical to
+    diagnostics=True, the status still rides in byte 54 of each record, and info carries no fp64 extras."""
+    n = 5000
+    rng = np.random.default_rng(5)
+    acts = [_uniform_actions(2e6, 1e-10, 3e-10)(rng, n, k) for k in range(3)]
+    kw = dict(device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=True, solver="rk4", seed=9,
+              autoreset=True, max_steps=2, out_layout=layout)
+    res = []
+    for diag in (True, False):
+        env = stg.SpinTorqueVecEnv(n, diagnostics=diag, **kw) if diag else stg.SpinTorqueVecEnv(n, **kw)
+        assert env.backend.diagnostics is diag
+        env.reset(seed=1)
+        out = []
+        for a in acts:
+            o, r, te, tr, info = env.step(torch.from_numpy(a))
+            if diag:
+                assert {"status", "reward_f64", "energy", "final_obs"} <= set(info)
+            else:
+                assert set(info) == ({"status"} if layout == "records" else set())
+                assert env.backend.reward64 is None and env.backend.energy is None and env.backend.final_obs is None
+            out.append((o.clone(), r.clone(), te.clone(), tr.clone(), info["status"].clone() if "status" in info else None))
+        om, rm, tem, trm, im = env.step_many(torch.from_numpy(np.stack(acts)))
+        assert ("reward_f64" in im) is diag
+        out.append((om.clone(), rm.clone(), tem.clone(), trm.clone(), im["status"].clone() if "status" in im else None))
+        out.append(env.get_state()["m"].clone())
+        res.append(out)
+        env.close()
+    for k in range(len(acts) + 1):
+        for x, y in zip(res[0][k][:4], res[1][k][:4]):
+            assert torch.equal(x, y), (layout, k)
+        if layout == "records":
+            assert torch.equal(res[0][k][4], res[1][k][4])
+    assert torch.equal(res[0][-1], res[1][-1])
+
+
+def test_misaligned_record_pointers_are_rejected(stg):
+    """the records layout stores float pairs; a record array or final_obs that is not 8-byte aligned is an
+    STG_E_INVALID from stg_reset / stg_step_many, not a GPU fault."""
+    import ctypes as C
+    from spin_torque_gym_amd import _lib
+    from spin_torque_gym_amd.backend import EnvConfig
+    lib = _lib.load()
+    n = 64
+    cfg = EnvConfig(solver="rk4", out_layout="records").to_abi()
+    ctx = C.c_void_p()
+    assert lib.stg_create(C.byref(ctx), 0, n, 0, C.byref(cfg)) == 0
+    p = stg.devices.flatten_params(stg.DeviceFactory().create_device("stt_mram", stt_default_params()))
+    assert lib.stg_set_params(ctx, C.byref(p), 1, None) == 0
+    dev = torch.device("cuda", 0)
+    raw = torch.zeros(n * 56 + 64, dtype=torch.uint8, device=dev)
+    fin = torch.zeros(n * 48 + 64, dtype=torch.uint8, device=dev)
+    act = torch.zeros((2, n), dtype=torch.float32, device=dev); act[1] = 1e-10
+    assert raw.data_ptr() % 8 == 0
+    good, bad = C.c_void_p(raw.data_ptr()), C.c_void_p(raw.data_ptr() + 4)
+    assert lib.stg_reset(ctx, None, None, None, C.c_uint64(0), bad, None) == _lib.STG_E_INVALID and b"aligned" in lib.stg_last_error()
+    assert lib.stg_reset(ctx, None, None, None, C.c_uint64(0), good, None) == 0
+    a = C.c_void_p(act.data_ptr())
+    assert lib.stg_step_many(ctx, 1, a, 0, 1, 1, bad, None, None, None, None, None, None, None, None) == _lib.STG_E_INVALID
+    assert lib.stg_step_many(ctx, 1, a, 0, 1, 1, good, C.c_void_p(fin.data_ptr() + 4), None, None, None, None, None, None, None) == _lib.STG_E_INVALID
+    assert b"final_obs" in lib.stg_last_error()
+    assert lib.stg_step_many(ctx, 1, a, 0, 1, 1, good, C.c_void_p(fin.data_ptr()), None, None, None, None, None, None, None) == 0
+    torch.cuda.synchronize()
+    lib.stg_destroy(ctx)
+
+
 @pytest.mark.parametrize("solver", ["rk4", "euler"])
 def test_ornstein_uhlenbeck_noise_model_vs_oracle(stg, solver):
     """noise_model='ou' (ThermalFluctuations' correlated field) on the fixed-step kernels against the
@@ -985,7 +1088,7 @@ def test_ornstein_uhlenbeck_noise_model_vs_oracle(stg, solver):
                   max_current=0.0 + 2e6)
         res = []
         for backend, ws in ((None, False), (None, True), (OracleBackend, None)):
-            env = stg.SpinTorqueVecEnv(n, backend=backend, wave_spec=ws, **kw)
+            env = stg.SpinTorqueVecEnv(n, diagnostics=True, backend=backend, wave_spec=ws, **kw)
             env.reset(options={"initial_state": m0, "target_state": tgt})
             out = []
             for a in acts:
@@ -1003,13 +1106,13 @@ def test_ornstein_uhlenbeck_noise_model_vs_oracle(stg, solver):
             d = np.abs(res[0][k][0] - res[2][k][0]).max()
             assert d <= 1e-8, (solver, multi, k, d)     # the normals carry fp32 device transcendentals (1e-7 relative)
         # the correlated field is not the white one
-        envw = stg.SpinTorqueVecEnv(n, **{**kw, "noise_model": "white"})
+        envw = stg.SpinTorqueVecEnv(n, diagnostics=True, **{**kw, "noise_model": "white"})
         envw.reset(options={"initial_state": m0, "target_state": tgt})
         envw.step(torch.from_numpy(acts[0] * np.array([0.0, 1.0], dtype=np.float32)))
         assert np.abs(envw.get_state()["m"].cpu().numpy() - res[0][0][0]).max() > 1e-6
         envw.close()
     with pytest.raises(Exception):
-        stg.SpinTorqueVecEnv(8, solver="rk45", noise_model="ou")
+        stg.SpinTorqueVecEnv(8, diagnostics=True, solver="rk45", noise_model="ou")
 
 
 @pytest.mark.parametrize("solver", ["rk4", "euler", "rk45"])
@@ -1130,8 +1233,8 @@ def test_per_env_parameters(stg, solver, thermal):
         tgt = np.where(rng.integers(0, 2, (n, 1)) == 0, 1.0, -1.0) * np.array([[0.0, 0.0, 1.0]])
         acts = [_uniform_actions(2e6, 1e-10, 2e-10)(rng, n, k) for k in range(2)]
         kw = dict(include_thermal_fluctuations=thermal, solver=solver, seed=5)
-        e1 = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(volume=vol0), per_env_params=ov, **kw)
-        e2 = stg.SpinTorqueVecEnv(n, device_type=["stt_mram"] * n, device_params=dicts(n, ov),
+        e1 = stg.SpinTorqueVecEnv(n, diagnostics=True, device_params=stt_default_params(volume=vol0), per_env_params=ov, **kw)
+        e2 = stg.SpinTorqueVecEnv(n, diagnostics=True, device_type=["stt_mram"] * n, device_params=dicts(n, ov),
                                   class_index=np.arange(n).astype(np.uint8), backend=backend_ref, **kw)
         outs = []
         for env in (e1, e2):
@@ -1155,7 +1258,7 @@ def test_per_env_parameters(stg, solver, thermal):
             assert outs[0][0][2][3] == 1              # STG_STATUS_NOOP for the env the validator gate rejects
     if solver == "rk4" and not thermal:
         n = 65536
-        env = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(volume=vol0), per_env_params=variation(n, False),
+        env = stg.SpinTorqueVecEnv(n, diagnostics=True, device_params=stt_default_params(volume=vol0), per_env_params=variation(n, False),
                                    include_thermal_fluctuations=True, solver=solver, seed=1, autoreset=True)
         env.reset(seed=0)
         a = torch.from_numpy(_uniform_actions(2e6, 1e-10, 3e-10)(rng, n, 0))
@@ -1179,7 +1282,7 @@ def test_switching_statistics_independent_streams(stg):
     m0 = np.array([0.05, 0.0, 1.0]); m0 /= np.linalg.norm(m0)
     stats = []
     for n, backend, seed in ((65536, None, 11), (4096, OracleBackend, 22)):
-        env = stg.SpinTorqueVecEnv(n, device_params=par, include_thermal_fluctuations=True, solver="rk4", seed=seed, backend=backend)
+        env = stg.SpinTorqueVecEnv(n, diagnostics=True, device_params=par, include_thermal_fluctuations=True, solver="rk4", seed=seed, backend=backend)
         env.reset(options={"initial_state": np.tile(m0, (n, 1)), "target_state": np.tile([0.0, 0.0, -1.0], (n, 1))})
         a = np.empty((n, 2), dtype=np.float32); a[:, 0] = 5e5; a[:, 1] = 2e-10
         _, _, te, tr, info = env.step(torch.from_numpy(a))
@@ -1204,7 +1307,7 @@ def test_schedule_covers_every_env_exactly_once(stg, n):
     acts = torch.from_numpy(_uniform_actions(2e6, 1e-10, 4e-10)(rng, n, 0))
     outs = []
     for ls in (False, True):
-        env = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=True,
+        env = stg.SpinTorqueVecEnv(n, diagnostics=True, device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=True,
                                    solver="rk4", seed=3, lane_sort=ls)
         env.reset(seed=7)
         o, r, te, tr, info = env.step(acts)
@@ -1227,7 +1330,7 @@ def test_rk45_zero_error_norm_and_fixed_points(stg):
     tgt = np.tile([0.0, 0.0, 1.0], (n, 1))
     res = []
     for backend in (None, OracleBackend):
-        env = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(), include_thermal_fluctuations=False, solver="rk45", backend=backend)
+        env = stg.SpinTorqueVecEnv(n, diagnostics=True, device_params=stt_default_params(), include_thermal_fluctuations=False, solver="rk45", backend=backend)
         env.reset(options={"initial_state": m0, "target_state": tgt})
         a = np.zeros((n, 2), dtype=np.float32); a[:, 1] = 2e-11
         o, r, te, tr, info = env.step(torch.from_numpy(a))
@@ -1252,7 +1355,7 @@ def test_results_do_not_depend_on_wavefront_composition(stg, solver):
     for thermal in (False, True):
         ref = None
         for rep in range(5):
-            env = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(volume=vol), include_thermal_fluctuations=thermal,
+            env = stg.SpinTorqueVecEnv(n, diagnostics=True, device_params=stt_default_params(volume=vol), include_thermal_fluctuations=thermal,
                                        solver=solver, seed=3)
             env.reset(seed=9)
             o, r, te, tr, info = env.step(torch.from_numpy(a))
@@ -1272,7 +1375,7 @@ def test_results_do_not_depend_on_wavefront_composition(stg, solver):
     for noise in ("white", "ou"):
         ref = None
         for rep in range(6):
-            env = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(volume=1e-27), include_thermal_fluctuations=True,
+            env = stg.SpinTorqueVecEnv(n, diagnostics=True, device_params=stt_default_params(volume=1e-27), include_thermal_fluctuations=True,
                                        solver=solver, seed=13, noise_model=noise, correlation_time=3e-12)
             env.reset(seed=9)
             env.step(torch.from_numpy(a))
@@ -1299,7 +1402,7 @@ def test_schedule_knobs_keep_the_slot_map_a_bijection(stg, monkeypatch, snake, w
         acts = torch.from_numpy(_uniform_actions(2e6, 1e-10, 2.5e-10)(rng, n, 0))
         outs = []
         for ls in (False, True):
-            env = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=False,
+            env = stg.SpinTorqueVecEnv(n, diagnostics=True, device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=False,
                                        solver="rk4", seed=3, lane_sort=ls)
             env.reset(seed=7)
             o, r, te, tr, info = env.step(acts)

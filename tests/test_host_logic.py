@@ -122,7 +122,7 @@ def test_params_validity_predicate(stg):
 
 def test_vec_env_layout_and_state_dict(stg):
     n = 6
-    env = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=False,
+    env = stg.SpinTorqueVecEnv(n, diagnostics=True, device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=False,
                                backend=OracleBackend, seed=3)
     with pytest.raises(RuntimeError):
         env.step(torch.zeros((n, 2)))
@@ -135,7 +135,7 @@ def test_vec_env_layout_and_state_dict(stg):
     assert tuple(obs.shape) == (n, 12) and r.dtype == torch.float32 and te.dtype == torch.bool
     sd = env.state_dict()
     o1, r1, *_ = env.step(a)
-    env2 = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=False,
+    env2 = stg.SpinTorqueVecEnv(n, diagnostics=True, device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=False,
                                 backend=OracleBackend, seed=3)
     env2.load_state_dict(sd)
     o2, r2, *_ = env2.step(a)
@@ -363,13 +363,13 @@ def test_checkpoint_resumes_noise_streams_in_a_fresh_unseeded_env(stg):
               backend=OracleBackend)
     rng = np.random.default_rng(0)
     acts = [np.stack([rng.uniform(-2e6, 2e6, n), rng.uniform(1e-10, 2e-10, n)], axis=1).astype(np.float32) for _ in range(3)]
-    e1 = stg.SpinTorqueVecEnv(n, seed=None, env_id0=640, **kw)
+    e1 = stg.SpinTorqueVecEnv(n, diagnostics=True, seed=None, env_id0=640, **kw)
     e1.reset(seed=3)
     e1.step(torch.from_numpy(acts[0]))
     sd = e1.state_dict()
     assert sd["cfg_seed"] == e1.cfg.seed and sd["env_id0"] == 640
     want = [tuple(t.clone() for t in e1.step(torch.from_numpy(a))[:4]) for a in acts[1:]]
-    e2 = stg.SpinTorqueVecEnv(n, seed=None, **kw)                 # another key, another env_id0
+    e2 = stg.SpinTorqueVecEnv(n, diagnostics=True, seed=None, **kw)                 # another key, another env_id0
     assert e2.cfg.seed != e1.cfg.seed
     e2.load_state_dict(sd)
     assert e2.cfg.seed == e1.cfg.seed and e2.env_id0 == 640
@@ -400,7 +400,7 @@ def test_performance_stats_timer_table(stg):
 
 def test_vector_env_spaces(stg):
     """gymnasium.vector.VectorEnv surface: num_envs, single_* and batched spaces."""
-    env = stg.SpinTorqueVecEnv(5, include_thermal_fluctuations=False, backend=OracleBackend)
+    env = stg.SpinTorqueVecEnv(5, diagnostics=True, include_thermal_fluctuations=False, backend=OracleBackend)
     assert env.num_envs == 5 and env.single_action_space.shape == (2,) and env.single_observation_space.shape == (12,)
     assert env.action_space.shape == (5, 2) and env.observation_space.shape == (5, 12)
     a = env.action_space.sample()

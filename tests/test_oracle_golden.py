@@ -217,11 +217,15 @@ def check_thermal_diffusion(g, solve_many, n_rk4, n_rk45, label):
         mean_our, rms_our = _diffusion_stats(ours, det)
         se = rms_ref / np.sqrt(len(ref))                      # standard error of the reference's sample mean
         assert np.all(np.abs(mean_our - mean_ref) < 5 * se), (label, solver, mean_our, mean_ref, se)
-        tol = 0.12 if solver == "rk4" else 0.2                # ~4 sigma of the rms estimate from 600 / 200 samples
+        # the reference's rms estimate from 4000 (rk4) / 1000 (rk45) samples has a relative standard error of 1.05 % / 2.0 %
+        # (|d|^2 has a coefficient of variation of 1.33 / 1.27; measured on the fixture), so 5 % / 8 % is 4-4.75 sigma of the
+        # REFERENCE's own estimate; our sample sizes keep our side's error below half of that
+        tol = 0.05 if solver == "rk4" else 0.08
+        assert len(ref) >= (4000 if solver == "rk4" else 1000)
         assert abs(rms_our / rms_ref - 1.0) < tol, (label, solver, rms_our, rms_ref)
         assert np.all(np.abs(np.linalg.norm(ours, axis=1) - 1) < 1e-12)
         if solver == "rk45":                                  # the noise also drives the step-size controller
-            assert abs(np.mean(npts) / np.mean(g["rk45_npts"] - 1) - 1.0) < 0.05, (np.mean(npts), np.mean(g["rk45_npts"]))
+            assert abs(np.mean(npts) / np.mean(g["rk45_npts"] - 1) - 1.0) < 0.02, (np.mean(npts), np.mean(g["rk45_npts"]))
         print(f"{label} {solver}: rms ours {rms_our:.3e} ref {rms_ref:.3e}")
 
 
@@ -251,7 +255,7 @@ def test_g10_thermal_on_vs_reference(golden, oracle_mod):
                 npts.append(r["n_points"] - 1)
             out.append(r["m_final"])
         return np.array(out), np.array(npts)
-    check_thermal_diffusion(g, solve_many, 3000, 1500, "oracle")
+    check_thermal_diffusion(g, solve_many, 12000, 6000, "oracle")
 
 
 def test_g11_simple_euler(golden, oracle_mod):
