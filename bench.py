@@ -29,7 +29,7 @@ per RK45 attempt -- more than the kernels execute, because they fold constants) 
 The counters are collected LIVE: at N = 1 this script first runs itself three times under `rocprofv3 --kernel-trace
 --pmc ...` (one pass per counter group: FETCH_SIZE and WRITE_SIZE cannot share one) on the same seeded workloads,
 BEFORE this process touches the GPU, and maps the dispatches to the rows through marker launches.  If rocprofv3 is not
-usable, the committed table profiles/r02_pmc_rows.json is used when it was measured on this very library build (sha256
+usable, the committed table profiles/r03_pmc_rows.json is used when it was measured on this very library build (sha256
 of the .so), and `frac`/`traffic` are null otherwise: no stale number is ever printed.
 """
 import argparse
@@ -55,6 +55,8 @@ for _p in (ROOT, os.path.join(ROOT, "spin-torque-rl-gym_amd")):
 # algorithmic work per unit
 BYTES_PER_ENV_STEP = 160          # homogeneous params: 68 B read + 90 B written (+2 B rounding in the survey's figure)
 BYTES_PER_ENV_STEP_MIXED = 161    # + 1 B class index
+BYTES_PER_ENV_STEP_PER_ENV = 272  # + 112 B: 14 fp64 parameters per env ("when params are per-env"); the library's
+                                  # record is the whole stg_device_params (30 fp64 + 2 B = 242 B), see `traffic`
 FLOPS_PER_RK4_SUBSTEP = 305       # reference formulation (work_equiv only)
 FLOPS_PER_RK45_ATTEMPT = 745
 PEAK_FP64_VALU_TFLOPS = 78.6      # MI355X vector fp64 (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz)
@@ -66,7 +68,7 @@ PMC_PASSES = {
     "fetch": "FETCH_SIZE",
     "write": "WRITE_SIZE",
 }
-PMC_TABLE = os.path.join(ROOT, "profiles", "r02_pmc_rows.json")
+PMC_TABLE = os.path.join(ROOT, "profiles", "r03_pmc_rows.json")
 MAIN_KERNELS = ("stg_step_kernel", "stg_array_step_kernel", "stg_array_step_individual_kernel")
 MARKER_KERNEL = "stg_normals_kernel"
 
@@ -126,6 +128,104 @@ def volume_for(solver):
     return 9.7e-6 if solver == "rk45" else 8.75e-11
 
 
+def host_limits():
+    """(CPUs the scheduler shows, CPUs this container may actually use per its CFS bandwidth quota)."""
+    vis = os.cpu_count() or 1
+    return vis, usable_cores(vis)
+
+
+def cap_host_threads():
+    """The GPU boxes show 256 CPUs but the container's CFS bandwidth quota is 16 (cgroup cpu.max = 1600000/100000): torch's
+    default intra-op pool of 128 OpenMP workers wakes up for every elementwise op / copy of the input generation, spins after
+    the parallel region and burns the quota of the 100 ms period, the kernel then THROTTLES the whole container until the next
+    period -- and a thread asleep in hipDeviceSynchronize cannot be woken meanwhile.  That was the "sporadic ~80 ms stall, once
+    per process" of rounds 1-2 (profiles/r03_stall_*: every stalled block coincides with nr_throttled += 1 in cpu.stat; none
+    without).  The pool is capped well below the quota; the step path itself is single-threaded on the host."""
+    vis, quota = host_limits()
+    n = max(1, min(4, quota))
+    torch.set_num_threads(n)
+    return {"cpus_visible": vis, "cpu_quota": quota, "torch_threads": n}
+
+
+class BlockTimer:
+    """Times blocks of EXACTLY `steps` calls of `body(k)` between synchronize (+ barrier) on both sides.
+
+    * every event exists and has been recorded once before the first block (torch creates the HIP event at the first
+      record()): nothing is created or allocated by the timing itself inside a block;
+    * the Python collector is off inside a block (one full pass before it): a generation-2 pass of this process takes
+      35-95 ms on the GPU boxes;
+    * the container's CFS throttling counters (cgroup cpu.stat) are read on both sides: `throttled` > 0 means the kernel
+      suspended this container during the block -- the measurement then contains up to 100 ms that are neither the GPU's nor
+      the program's, and the caller may time another block.  That is the only re-timing criterion; it does not look at
+      the times measured."""
+
+    def __init__(self, dev, steps, world=1):
+        self.dev, self.steps, self.world = dev, steps, world
+        self.starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        self.ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        self.fin = torch.cuda.Event(enable_timing=True)
+        for e in (*self.starts, *self.ends, self.fin):
+            e.record()
+        torch.cuda.synchronize(dev)
+
+    def block(self, body, tail=None):
+        import gc
+        import torch.distributed as dist
+        gc.collect()
+        gc.disable()
+        try:
+            cg0 = cgroup_cpu_stat()
+            if self.world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(self.dev)
+            t0 = time.perf_counter()
+            for k in range(self.steps):
+                self.starts[k].record()
+                body(k)
+                self.ends[k].record()
+            if tail is not None:
+                tail()
+            self.fin.record()
+            torch.cuda.synchronize(self.dev)
+            if self.world > 1:
+                dist.barrier()
+            t1 = time.perf_counter()
+            cg1 = cgroup_cpu_stat()
+        finally:
+            gc.enable()
+        return {"wall_s": t1 - t0, "kernel_ms": [s_.elapsed_time(e) for s_, e in zip(self.starts, self.ends)],
+                "device_span_s": self.starts[0].elapsed_time(self.fin) * 1e-3,
+                "throttled": cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0),
+                "throttled_usec": cg1.get("throttled_usec", 0) - cg0.get("throttled_usec", 0)}
+
+    def timed(self, body, tail=None, retime=True, tag="", pre=None):
+        """-> (last block, all blocks).  A block during which the container was throttled is followed by another (twice at
+        most).  `pre` runs before every block, outside the timed region (e.g. resetting the on-device work counters)."""
+        import torch.distributed as dist
+        blocks = []
+        while True:
+            if pre is not None:
+                pre()
+            b = self.block(body, tail)
+            thr = float(b["throttled"] > 0)
+            if self.world > 1:
+                flag = torch.tensor([thr], dtype=torch.float64, device=self.dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                thr = float(flag.item())
+            blocks.append(b)
+            if os.environ.get("STG_BENCH_DEBUG"):
+                print("debug %s: block %d wall %.3f ms, device span %.3f ms, sum of kernel times %.3f ms, throttled %d (%d us)" % (
+                    tag, len(blocks), b["wall_s"] * 1e3, b["device_span_s"] * 1e3, sum(b["kernel_ms"]), b["throttled"], b["throttled_usec"]),
+                    file=sys.stderr, flush=True)
+            if not thr or len(blocks) >= 3 or not retime:
+                return b, blocks
+
+
+def block_report(blocks):
+    return {"blocks_timed": len(blocks), "block_walls_ms": [round(b["wall_s"] * 1e3, 4) for b in blocks],
+            "block_throttled": [int(b["throttled"]) for b in blocks]}
+
+
 def cgroup_cpu_stat():
     """CPU-bandwidth statistics of this container (cgroup v2 cpu.stat, v1 fallback): nr_periods, nr_throttled, throttled_usec."""
     for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
@@ -155,26 +255,52 @@ class Marker:
             torch.cuda.synchronize(self.b.device)
 
 
+def per_env_variation(n, seed=11):
+    """Device-to-device variation of the per-env-parameter cfg4 row (and of its test, tests/test_gpu_fullsize.py): every
+    env gets its own volume, damping, anisotropy, magnetisation, polarisation and parallel resistance around its base
+    device's values (reference keys; arrays of length n)."""
+    rng = np.random.default_rng(seed)
+    return {"volume_scale": 10 ** rng.uniform(-0.15, 0.15, n), "damping": 10 ** rng.uniform(-2.2, -1.3, n),
+            "uniaxial_anisotropy": rng.uniform(8e5, 1.2e6, n), "saturation_magnetization": rng.uniform(7e5, 9e5, n),
+            "polarization": rng.uniform(0.5, 0.9, n), "resistance_parallel": rng.uniform(900.0, 1300.0, n)}
+
+
+def mixed_kwargs(solver, n_global, per_env=False):
+    """cfg4: class = env index mod 3 over STT / SOT / VCMA, factory defaults of each type with polarization 0.7 and the
+    rescaled volume; per_env: on top of that every env's own record (stg_set_params_per_env)."""
+    import spin_torque_gym_amd as stg
+    fac = stg.DeviceFactory()
+    sot = fac.get_default_parameters("sot_mram"); sot.update(polarization=0.7, volume=volume_for(solver))
+    vc = fac.get_default_parameters("vcma_mram"); vc.update(polarization=0.7, volume=volume_for(solver))
+    kw = dict(device_type=["stt_mram", "sot_mram", "vcma_mram"], device_params=[stt_params(volume_for(solver)), sot, vc])
+    cls = (torch.arange(n_global) % 3).to(torch.uint8)
+    if per_env:
+        v = per_env_variation(n_global)
+        ov = {k: val for k, val in v.items() if k != "volume_scale"}
+        ov["volume"] = volume_for(solver) * v["volume_scale"]
+        kw["per_env_params"] = ov
+    return kw, cls
+
+
 def run_config(n_local, solver, thermal, steps, warmup, rank, world, device_index, mixed=False, seed=1234, lane_sort=None,
-               torque_model="reference", wave_spec=None, gather_algo="all_gather", retime=True):
-    """Builds the env, runs warmup + timed steps, returns a dict of measurements (times are this rank's)."""
+               torque_model="reference", wave_spec=None, gather_algo="all_gather", retime=True, per_env=False, api=False,
+               inplace=False, extras=True):
+    """Builds the env, runs warmup + timed steps, returns a dict of measurements (times are this rank's).
+    The env is the product default: diagnostics off (a step writes the RL-facing outputs only), records layout."""
     import spin_torque_gym_amd as stg
     import torch.distributed as dist
     kw = dict(include_thermal_fluctuations=bool(thermal), temperature=300.0, solver=solver, seed=seed, autoreset=True,
               lane_sort=lane_sort, torque_model=torque_model, wave_spec=wave_spec)
     if mixed:
-        fac = stg.DeviceFactory()
-        sot = fac.get_default_parameters("sot_mram"); sot.update(polarization=0.7, volume=volume_for(solver))
-        vc = fac.get_default_parameters("vcma_mram"); vc.update(polarization=0.7, volume=volume_for(solver))
-        kw.update(device_type=["stt_mram", "sot_mram", "vcma_mram"], device_params=[stt_params(volume_for(solver)), sot, vc])
-        cls_global = (torch.arange(n_local * world) % 3).to(torch.uint8)
+        mk, cls_global = mixed_kwargs(solver, n_local * world, per_env)
+        kw.update(mk)
     else:
         kw.update(device_params=stt_params(volume_for(solver)))
         cls_global = None
     if world > 1:
         from spin_torque_gym_amd.distributed import ShardedSpinTorqueVecEnv
         env = ShardedSpinTorqueVecEnv(n_local * world, device_index=device_index, class_index=cls_global,
-                                      gather_algo=gather_algo, **kw)
+                                      gather_algo=gather_algo, inplace=inplace, **kw)
         backend = env.local.backend
     else:
         env = stg.SpinTorqueVecEnv(n_local, device_index=device_index, class_index=cls_global, **kw)
@@ -190,120 +316,88 @@ def run_config(n_local, solver, thermal, steps, warmup, rank, world, device_inde
 
     def one_step(k, gather=True):
         """world > 1: the step kernel writes its 56-byte records into this rank's slice of a global record array; step
-        k-1's in-place all-gather (own stream) runs under step k's kernel; gather_end hands out typed views -- what a
-        learner consumes, no copies (spin_torque_gym_amd/distributed.py)."""
+        k-1's all-gather (own stream) runs under step k's kernel; gather_end hands out typed views -- what a learner
+        consumes, no copies (spin_torque_gym_amd/distributed.py)."""
         if world == 1:
-            backend.step(acts[k], autoreset=True)
+            backend.step(acts[k], autoreset=True)                    # the step kernel, on torch's current stream
             return
         env.step(acts[k], gather=False, actions_are_local=True, actions_soa=True)
         if gather:
             if env.gather_in_flight:
-                env.gather_end()
-            env.gather_begin()
+                env.gather_end()                                     # step k-1's gather ran under step k's kernel
+            env.gather_begin()                                       # the single collective of a step, on its own stream
+
+    def drain():
+        if world > 1 and env.gather_in_flight:
+            env.gather_end()                                         # (typed global views: obs [N,12], reward, flags)
 
     for k in range(warmup):
         one_step(k)
-    if world > 1 and env.gather_in_flight:
+    drain()
+    torch.cuda.synchronize(dev)
+    timer = BlockTimer(dev, steps, world)
+    tag = "n=%d %s th=%s tm=%s%s" % (n_local, solver, thermal, torque_model, " per-env" if per_env else "")
+    last, blocks = timer.timed(lambda k: one_step(warmup + k), drain, retime, tag, pre=lambda: backend.counters(reset=True))
+    c = backend.counters()                                           # work units of the last (= reported) block
+    out = dict(wall_s=last["wall_s"], device_span_s=last["device_span_s"], kernel_ms_avg=float(np.mean(last["kernel_ms"])),
+               kernel_ms_min=float(np.min(last["kernel_ms"])), env_steps=c["env_steps"], work_units=c["work_units"],
+               noop_steps=c["noop_steps"], launches=steps, warmup=warmup, **block_report(blocks))
+    out.update(gather_only_ms=None, wall_no_gather_s=None, api_ms_per_step=None)
+    if world > 1 and extras:
+        # SURVEY 8e "report both": a learner that is data-parallel over the same ranks needs no gather at all
+        out["wall_no_gather_s"] = timer.timed(lambda k: one_step(warmup + k, gather=False), None, retime, tag + " no-gather")[0]["wall_s"]
+    if world > 1:
+        out["gather_only_ms"] = gather_only(env, acts[warmup], steps, dev)
+    if api and world == 1:
+        # the public API: SpinTorqueVecEnv.step() with Gym-convention [N, 2] actions (host-side views, the transposition of
+        # the actions into the kernel's [2, N], the timer table, the info dict) -- what a user's loop pays per step
+        acts_gym = acts[warmup:].transpose(1, 2).contiguous()
+        env.step(acts_gym[0])
+        torch.cuda.synchronize(dev)
+        out["api_ms_per_step"] = timer.timed(lambda k: env.step(acts_gym[k]), None, retime, tag + " api")[0]["wall_s"] / steps * 1e3
+    env.close()
+    return out
+
+
+def gather_only(env, act, steps, dev):
+    """The exchange by itself (nothing to hide under): `steps` exchanges of one step's records back to back, ms each."""
+    import torch.distributed as dist
+    env.step(act, gather=False, actions_are_local=True, actions_soa=True)
+    env.gather_begin()
+    env.gather_end()                                                 # (first use of this algorithm's communicator path)
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        env.gather_again()                                           # (re-send the records of the step above)
+        env.gather_begin()
         env.gather_end()
     torch.cuda.synchronize(dev)
+    dist.barrier()
+    return (time.perf_counter() - t0) / steps * 1e3
 
-    gc_log = []          # (generation, start offset in s from the block's t0, duration in s) of every collector pass
 
-    def timed_block(gather=True):
-        """EXACTLY `steps` steps between barrier + synchronize on both sides; also the same span seen from the device."""
-        backend.counters(reset=True)
-        debug = bool(os.environ.get("STG_BENCH_DEBUG"))
-        host_t = []
-        gc_t = [0.0]
-
-        def _gc_cb(phase, info):
-            if phase == "start":
-                gc_t[0] = time.perf_counter()
-            else:
-                gc_log.append((info["generation"], gc_t[0], time.perf_counter() - gc_t[0]))
-        if debug:
-            import gc
-            gc.callbacks.append(_gc_cb)
-        cg0 = cgroup_cpu_stat()
-        starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
-        ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
-        fin = torch.cuda.Event(enable_timing=True)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for k in range(steps):
-            if debug:
-                host_t.append(time.perf_counter())
-            starts[k].record()
-            if world == 1:
-                backend.step(acts[warmup + k], autoreset=True)       # the step kernel, on torch's current stream
-                ends[k].record()
-            else:
-                env.step(acts[warmup + k], gather=False, actions_are_local=True, actions_soa=True)
-                ends[k].record()
-                if gather:
-                    if env.gather_in_flight:
-                        env.gather_end()                             # step k-1's gather ran under step k's kernel
-                    env.gather_begin()                               # the single collective of a step, on its own stream
-        if world > 1 and gather:
-            env.gather_end()                                         # (typed global views: obs [N,12], reward, flags)
-        fin.record()
-        t_enq = time.perf_counter()
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        t1 = time.perf_counter()
-        if debug:
-            import gc
-            gc.callbacks.remove(_gc_cb)
-            cg1 = cgroup_cpu_stat()
-            print("debug host: enqueue of %d steps %.3f ms, synchronize %.3f ms; gc passes in block: %s; cgroup cpu.stat delta over the block: %s" % (
-                steps, (t_enq - t0) * 1e3, (t1 - t_enq) * 1e3,
-                [(g, round((a - t0) * 1e3, 3), round(d * 1e3, 3)) for g, a, d in gc_log if a >= t0],
-                {k: cg1.get(k, 0) - cg0.get(k, 0) for k in ("nr_periods", "nr_throttled", "throttled_usec")}), file=sys.stderr, flush=True)
-        return t1 - t0, [s.elapsed_time(e) for s, e in zip(starts, ends)], starts[0].elapsed_time(fin) * 1e-3
-
-    # The GPU boxes of this pool show a sporadic ~80 ms hiccup (the device finishes -- its own event timestamps are
-    # back-to-back -- but the host's synchronize returns late; seen in any configuration, about once per process).  A
-    # block whose wall time exceeds what the device itself measured for the same span by more than 25 % + 2 ms is
-    # re-timed (at most twice); `blocks_timed` in the output says how many blocks were run.  Every block is exactly
-    # `steps` steps and the reported time is always host wall-clock time of one whole block.
-    blocks = 0
-    while True:
-        blocks += 1
-        wall, kern_ms, dev_span = timed_block()
-        hiccup = 1.0 if wall > 1.25 * dev_span + 2e-3 else 0.0
-        if world > 1:
-            flag = torch.tensor([hiccup], dtype=torch.float64, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            hiccup = float(flag.item())
-        if os.environ.get("STG_BENCH_DEBUG"):
-            print("debug run_config n=%d %s th=%s tm=%s: block %d wall %.3f ms, device span %.3f ms, kernel ms %s" % (
-                n_local, solver, thermal, torque_model, blocks, wall * 1e3, dev_span * 1e3, [round(x, 3) for x in kern_ms]),
-                file=sys.stderr, flush=True)
-        if not hiccup or blocks >= 3 or not retime:
-            break
-    c = backend.counters()
-    # SURVEY 8e "report both": a learner that is data-parallel over the same ranks needs no gather at all
-    wall_ng = timed_block(gather=False)[0] if (world > 1 and retime) else None
-    gather_only_ms = None
-    if world > 1 and retime:
-        # the collective by itself (nothing to hide under): `steps` exchanges of the last step's records back to back
-        env.step(acts[warmup], gather=False, actions_are_local=True, actions_soa=True)
-        torch.cuda.synchronize(dev)
-        dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            env.gather_again()                       # (re-send the records of the step above)
-            env.gather_begin()
-            env.gather_end()
-        torch.cuda.synchronize(dev)
-        dist.barrier()
-        gather_only_ms = (time.perf_counter() - t0) / steps * 1e3
-    env.close()
-    return dict(gather_only_ms=gather_only_ms, wall_no_gather_s=wall_ng, wall_s=wall, device_span_s=dev_span, blocks_timed=blocks, kernel_ms_avg=float(np.mean(kern_ms)), kernel_ms_min=float(np.min(kern_ms)),
-                env_steps=c["env_steps"], work_units=c["work_units"], noop_steps=c["noop_steps"], launches=steps, warmup=warmup)
+def gather_only_all_algos(n_local, solver, thermal, steps, rank, world, device_index, seed=1234):
+    """N > 1: the exchange by itself for the three forms -- RCCL all-gather out of place (default), in place, and the
+    one-shot point-to-point exchange -- in ONE run, so that the first multi-GPU lease yields the choice."""
+    import torch.distributed as dist
+    from spin_torque_gym_amd.distributed import ShardedSpinTorqueVecEnv
+    out = {}
+    for name, algo, inplace in (("all_gather", "all_gather", False), ("all_gather_inplace", "all_gather", True), ("p2p", "p2p", False)):
+        try:
+            env = ShardedSpinTorqueVecEnv(n_local * world, device_index=device_index, gather_algo=algo, inplace=inplace,
+                                          include_thermal_fluctuations=bool(thermal), solver=solver, seed=seed, autoreset=True,
+                                          device_params=stt_params(volume_for(solver)))
+            dev = env.local.backend.device
+            env.reset(seed=seed + rank)
+            act = make_actions(1, n_local, dev, seed + 17 * rank)[0]
+            ms = torch.tensor([gather_only(env, act, steps, dev)], dtype=torch.float64, device=dev)
+            dist.all_reduce(ms, op=dist.ReduceOp.MAX)
+            out[name] = round(float(ms.item()), 4)
+            env.close()
+        except Exception as e:          # noqa: BLE001 -- an algorithm RCCL refuses must not cost the run its headline number
+            out[name] = f"failed: {type(e).__name__}: {e}"[:200]
+    return out
 
 
 def run_array_config(n, mode, steps, device_index, size=(4, 4), retime=True):
@@ -328,24 +422,13 @@ def run_array_config(n, mode, steps, device_index, size=(4, 4), retime=True):
     for k in range(2):
         env.backend.step(acts[k])
     torch.cuda.synchronize(dev)
-    for _ in range(3 if retime else 1):    # re-timed after a host-side hiccup, as in run_config
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for k in range(steps):
-            ev[k][0].record()
-            env.backend.step(acts[k + 2])
-            ev[k][1].record()
-        torch.cuda.synchronize(dev)
-        wall = time.perf_counter() - t0
-        if wall <= 1.25 * ev[0][0].elapsed_time(ev[-1][1]) * 1e-3 + 2e-3:
-            break
-    ms = float(np.mean([x.elapsed_time(y) for x, y in ev]))
+    last, blocks = BlockTimer(dev, steps).timed(lambda k: env.backend.step(acts[k + 2]), None, retime, f"array {mode}")
     env.close()
     affected = {"individual": 1, "row": size[1], "column": size[0], "global": ndev}[mode]
     # algorithmic bytes per array-step: pattern + target + state + action read; addressed cells, obs, reward, flags, state written
     b = (ndev * 24 * 2 + 12 + 4 * a_dim) + (affected * 24 + ndev * 24 + 4 + 2 + 12 + 16)
-    return dict(kind="array", wall_s=wall, kernel_ms_avg=ms, launches=steps, warmup=2, n=n, bytes_per_unit=b,
+    return dict(kind="array", wall_s=last["wall_s"], kernel_ms_avg=float(np.mean(last["kernel_ms"])), launches=steps, warmup=2, n=n, bytes_per_unit=b,
+                **block_report(blocks),
                 workload=f"SpinTorqueArray-v0: {n} arrays of {size[0]}x{size[1]} STT cells, action_mode={mode}, dipolar coupling",
                 kernel="stg_array_step_individual_kernel" if mode == "individual" else "stg_array_step_kernel")
 
@@ -360,29 +443,17 @@ def run_short_pulse_config(n, steps, device_index, K=1, retime=True):
     b = env.backend
     a = torch.zeros((K, 2, n), dtype=torch.float32, device=b.device)
     a[:, 1] = 1e-12
-    call = (lambda: b.step(a[0], autoreset=True)) if K == 1 else (lambda: b.step_many(a, out_every=False, autoreset=True))
+    call = (lambda k: b.step(a[0], autoreset=True)) if K == 1 else (lambda k: b.step_many(a, out_every=False, autoreset=True))
     for _ in range(2):
-        call()
-    for _ in range(3 if retime else 1):    # re-timed after a host-side hiccup, as in run_config
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-        torch.cuda.synchronize(b.device)
-        b.counters(reset=True)
-        t0 = time.perf_counter()
-        for k in range(steps):
-            ev[k][0].record()
-            call()
-            ev[k][1].record()
-        torch.cuda.synchronize(b.device)
-        wall = time.perf_counter() - t0
-        if wall <= 1.25 * ev[0][0].elapsed_time(ev[-1][1]) * 1e-3 + 2e-3:
-            break
-    ms = float(np.mean([x.elapsed_time(y) for x, y in ev]))
+        call(0)
+    torch.cuda.synchronize(b.device)
+    last, blocks = BlockTimer(b.device, steps).timed(call, None, retime, f"cfg2a K={K}", pre=lambda: b.counters(reset=True))
     c = b.counters()
     env.close()
     # state read and written once per launch, actions read K times, outputs written once (out_every = False)
-    return dict(kind="short", wall_s=wall, kernel_ms_avg=ms, launches=steps, warmup=2, n=n, K=K,
+    return dict(kind="short", wall_s=last["wall_s"], kernel_ms_avg=float(np.mean(last["kernel_ms"])), launches=steps, warmup=2, n=n, K=K,
                 bytes_per_launch=BYTES_PER_ENV_STEP * n + 8 * n * (K - 1), env_steps=c["env_steps"], work_units=c["work_units"],
-                noop_steps=c["noop_steps"],
+                noop_steps=c["noop_steps"], **block_report(blocks),
                 workload=f"cfg2a: {n} STT envs, T=0K, rk45, every pulse = one 1 ps DP5 step, {K} env-step(s) per launch")
 
 
@@ -394,23 +465,25 @@ def row_specs(args):
     lane_sort = {"auto": None, "on": True, "off": False}[args.lane_sort]
     wave_spec = {"auto": None, "on": True, "off": False}[args.wave_spec]
     st = max(3, args.steps // 2)
-    rows = [("headline", dict(kind="step", n=args.envs_per_gpu, solver=args.solver, thermal=args.thermal, mixed=False,
-                              tm="reference", steps=args.steps, warmup=args.warmup, lane_sort=lane_sort, wave_spec=wave_spec))]
+    rows = [("headline", dict(kind="step", n=args.envs_per_gpu, solver=args.solver, thermal=args.thermal, mixed=False, per_env=False,
+                              tm="reference", steps=args.steps, warmup=args.warmup, lane_sort=lane_sort, wave_spec=wave_spec, api=True))]
     if not args.also:
         return rows
-    for name, n, solver, thermal, mixed, tm in (
-            ("cfg2: 4096 STT envs, T=0K, rk45", 4096, "rk45", 0, False, "reference"),
-            ("cfg2: 4096 STT envs, T=0K, rk4 (the env's own solver)", 4096, "rk4", 0, False, "reference"),
-            ("cfg3: 65536 STT envs, thermal on, rk4", 65536, "rk4", 1, False, "reference"),
-            ("cfg5 shard: 131072 STT envs (1 048 576 over 8 GPUs), thermal on, rk45", 131072, "rk45", 1, False, "reference"),
+    for name, n, solver, thermal, mixed, tm, per_env, api in (
+            ("cfg2: 4096 STT envs, T=0K, rk45", 4096, "rk45", 0, False, "reference", False, True),
+            ("cfg2: 4096 STT envs, T=0K, rk4 (the env's own solver)", 4096, "rk4", 0, False, "reference", False, False),
+            ("cfg3: 65536 STT envs, thermal on, rk4", 65536, "rk4", 1, False, "reference", False, False),
+            ("cfg5 shard: 131072 STT envs (1 048 576 over 8 GPUs), thermal on, rk45", 131072, "rk45", 1, False, "reference", False, False),
             ("cfg4: 262144 mixed STT/SOT/VCMA envs (class table in LDS), T=0K, rk4, reference RHS for all types",
-             262144, "rk4", 0, True, "reference"),
+             262144, "rk4", 0, True, "reference", False, False),
             ("cfg4: 262144 mixed STT/SOT/VCMA envs, T=0K, rk4, device-physics torque terms per type (opt-in)",
-             262144, "rk4", 0, True, "device")):
+             262144, "rk4", 0, True, "device", False, False),
+            ("cfg4 per-env: 262144 mixed STT/SOT/VCMA envs, every env its own parameter record (stg_set_params_per_env), T=0K, rk4",
+             262144, "rk4", 0, True, "reference", True, False)):
         if solver == args.solver and n == args.envs_per_gpu and bool(thermal) == bool(args.thermal) and not mixed:
             continue
-        rows.append((name, dict(kind="step", n=n, solver=solver, thermal=thermal, mixed=mixed, tm=tm, steps=st, warmup=2,
-                                lane_sort=None, wave_spec=None)))
+        rows.append((name, dict(kind="step", n=n, solver=solver, thermal=thermal, mixed=mixed, per_env=per_env, tm=tm, steps=st, warmup=2,
+                                lane_sort=None, wave_spec=None, api=api)))
     for K in (1, 8):
         rows.append((f"cfg2a K={K}", dict(kind="short", n=1048576, K=K, steps=st)))
     for mode in ("individual", "global"):
@@ -418,11 +491,11 @@ def row_specs(args):
     return rows
 
 
-def run_row(spec, rank, world, local_rank, retime=True, gather_algo="all_gather"):
+def run_row(spec, rank, world, local_rank, retime=True, gather_algo="all_gather", api=True):
     if spec["kind"] == "step":
         m = run_config(spec["n"], spec["solver"], spec["thermal"], spec["steps"], spec["warmup"], rank, world, local_rank,
                        mixed=spec["mixed"], torque_model=spec["tm"], lane_sort=spec["lane_sort"], wave_spec=spec["wave_spec"],
-                       gather_algo=gather_algo, retime=retime)
+                       gather_algo=gather_algo, retime=retime, per_env=spec["per_env"], api=api and spec["api"])
         m["kind"] = "step"
         return m
     if spec["kind"] == "short":
@@ -439,7 +512,7 @@ def pmc_child(args):
     manifest = []
     for key, spec in row_specs(args):
         mk.mark()
-        m = run_row(spec, 0, 1, 0, retime=False)
+        m = run_row(spec, 0, 1, 0, retime=False, api=False)
         manifest.append({"key": key, "launches": m["launches"], "warmup": m["warmup"]})
     mk.mark()
     with open(args.pmc_child, "w") as f:
@@ -559,7 +632,7 @@ def pmc_for_run(args, argv, live=True):
         return None, f"{note}; the committed table was measured on another library build"
     if committed.get("workload") != workload_key(args):
         return None, f"{note}; the committed table was measured on other workload arguments"
-    return committed["rows"], (f"{note}; committed table profiles/r02_pmc_rows.json (same library sha256, same workload arguments, "
+    return committed["rows"], (f"{note}; committed table profiles/r03_pmc_rows.json (same library sha256, same workload arguments, "
                                f"measured with --steps {committed.get('steps')})")
 
 
@@ -583,19 +656,22 @@ def exec_block(c, kernel_s):
             if c.get("SQ_INSTS_VALU") else None}
 
 
-def roofline_step(meas, n_local, solver, mixed, pmc_row, pmc_src):
+def roofline_step(meas, n_local, solver, mixed, pmc_row, pmc_src, per_env=False):
     """fp64-VALU-bound rows (a full env-step)."""
+    bpe = BYTES_PER_ENV_STEP_PER_ENV if per_env else (BYTES_PER_ENV_STEP_MIXED if mixed else BYTES_PER_ENV_STEP)
     c = (pmc_row or {}).get("counters")
     t = meas["kernel_ms_avg"] * 1e-3
     ex = exec_block(c, t)
     flops_per_unit = FLOPS_PER_RK45_ATTEMPT if solver == "rk45" else FLOPS_PER_RK4_SUBSTEP
     units_per_launch = meas["work_units"] / meas["launches"]
     we = flops_per_unit * units_per_launch / t / 1e12
-    bytes_per_launch = (BYTES_PER_ENV_STEP_MIXED if mixed else BYTES_PER_ENV_STEP) * n_local
+    bytes_per_launch = bpe * n_local
     gbs = bytes_per_launch / t / 1e9
+    tb = traffic_bytes(c)
     return {"bound": "valu_fp64", "achieved": round(ex["tflops"], 4) if ex else None, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ex["tflops"] / PEAK_FP64_VALU_TFLOPS, 5) if ex else None,
-            "traffic": traffic_bytes(c), "algorithmic_bytes": bytes_per_launch,
+            "traffic": tb, "algorithmic_bytes": bytes_per_launch,
+            "traffic_over_algorithmic": round(tb / bytes_per_launch, 3) if tb else None,
             "basis": "executed: 64 x (2 FMA_F64 + MUL_F64 + ADD_F64) wavefront instructions per launch (hardware counters) / "
                      "HIP-event kernel time",
             "valu_issue_frac": round(ex["valu_issue_frac"], 4) if ex and ex["valu_issue_frac"] is not None else None,
@@ -607,7 +683,7 @@ def roofline_step(meas, n_local, solver, mixed, pmc_row, pmc_src):
                            "note": "reference formulation's flop count (SURVEY 8d) x work units / time: how fast the reference's "
                                    "arithmetic gets done; the kernels fold constants and execute fewer -- NOT a roofline fraction"},
             "hbm": {"achieved": round(gbs, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 7),
-                    "bytes_per_env_step": BYTES_PER_ENV_STEP_MIXED if mixed else BYTES_PER_ENV_STEP},
+                    "bytes_per_env_step": bpe},
             "pmc_source": pmc_src}
 
 
@@ -666,7 +742,7 @@ def cpu_baseline(solver, thermal, seconds):
     tgt = np.where(rng.integers(0, 2, (n, 1)) == 0, 1.0, -1.0) * np.array([[0.0, 0.0, 1.0]])
     p = (oracle.Params * 1)(oracle.make_params(stt_params(volume_for(solver))))
     c = oracle.make_config(solver=solver, thermal=bool(thermal), seed=1234)
-    threads = usable_cores(oracle.lib().stgo_max_threads())
+    threads = host_limits()[1]        # every CPU the container's quota allows (the torch pool's cap does not apply here)
     done_steps, t_used, batches = 0, 0.0, 0
     while t_used < seconds and batches < 4096:
         st = make_states(n, m0, tgt)
@@ -689,6 +765,26 @@ def child_argv(args):
             "--wave-spec", args.wave_spec, "--pmc", "off"]
 
 
+def check_ranks(args, rank, local_rank, world):
+    """N > 1: every rank reports (rank, local device index, PCI domain/bus/device of its GPU) through the process group
+    itself; asserts that the collective library really spans `--gpus` ranks and, with RCCL, that no two ranks share a GPU."""
+    import torch.distributed as dist
+    dev = torch.device("cuda", local_rank)
+    pr = torch.cuda.get_device_properties(local_rank)
+    mine = torch.tensor([rank, local_rank, getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)],
+                        dtype=torch.int64, device=dev)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    rows = [tuple(int(x) for x in t.tolist()) for t in allr]
+    if dist.get_world_size() != args.gpus or sorted(r[0] for r in rows) != list(range(args.gpus)):
+        raise SystemExit(f"process group has ranks {sorted(r[0] for r in rows)}, expected 0..{args.gpus - 1}")
+    gpus = {r[2:] for r in rows}
+    if args.backend == "nccl" and len(gpus) != world:
+        raise SystemExit(f"{world} RCCL ranks on {len(gpus)} distinct GPUs: {rows}")
+    return {"ranks_seen": len(rows), "distinct_gpus": len(gpus), "backend": dist.get_backend(),
+            "pci": ["%04x:%02x:%02x" % r[2:] for r in sorted(rows)]}
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -697,6 +793,7 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    host = cap_host_threads()
     if args.pmc_child:
         pmc_child(args)
         return
@@ -711,9 +808,12 @@ def main():
                 print("debug gc: generation %d pass took %.3f ms (collected %d) at t=%.3f s" % (
                     info["generation"], (time.perf_counter() - _g0[0]) * 1e3, info["collected"], time.perf_counter()), file=sys.stderr, flush=True)
         gc.callbacks.append(_gc_all)
+        print("debug host:", host, "cgroup cpu.stat at start:", {k: v for k, v in cgroup_cpu_stat().items() if "thrott" in k or k == "nr_periods"},
+              file=sys.stderr, flush=True)
     # hardware counters first: the child passes must be started before this process initialises the GPU
     pmc_tab, pmc_src = pmc_for_run(args, child_argv(args), live=(world == 1)) if rank == 0 else (None, "rank > 0")
     import torch.distributed as dist
+    ranks = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         ndev = torch.cuda.device_count()
@@ -724,6 +824,7 @@ def main():
             local_rank = local_rank % max(ndev, 1)          # rehearsal: several ranks may share one GPU
             torch.cuda.set_device(local_rank)
             dist.init_process_group(args.backend)
+        ranks = check_ranks(args, rank, local_rank, world)
     n_local = args.envs_per_gpu
     specs = row_specs(args)
     row = lambda key: (pmc_tab or {}).get(key)
@@ -737,18 +838,26 @@ def main():
         "metric": "env_steps_per_sec", "value": round(n_total * args.steps / wall_s, 1), "unit": "env-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall_s / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "blocks_timed": meas["blocks_timed"],
+        "api_ms_per_step": round(meas["api_ms_per_step"], 4) if meas.get("api_ms_per_step") else None,
         "no_gather": None,
         "config": {"workload": f"cfg3: {n_local} STT-MRAM envs/GPU, thermal {'on 300K (in-kernel Philox)' if args.thermal else 'off'}, "
                                f"solver={args.solver} ({'LLGSSolver SciPy-RK45 rtol1e-6 atol1e-9 max_step 1ps' if args.solver == 'rk45' else 'SimpleLLGSSolver fixed-step dt<=1ps'}), "
-                               f"full env.step, J~U[-2e6,2e6], pulse~U[0.1,1]ns f32, volume={volume_for(args.solver):g}, autoreset",
+                               f"full env.step, J~U[-2e6,2e6], pulse~U[0.1,1]ns f32, volume={volume_for(args.solver):g}, autoreset, "
+                               f"diagnostics off (the step writes obs/reward/terminated/truncated only)",
                    "envs_per_gpu": n_local, "global_envs": n_total, "solver": args.solver, "thermal": bool(args.thermal),
                    "parallelism": (f"env-sharded x{world}; per step ONE {args.gather_algo} of 56 B/env records (written by the step kernel straight into the send buffer) into the "
                                    f"global record array, pipelined under the next kernel; the timed loop hands out the learner's typed views "
                                    f"(obs [N,12], reward, terminated, truncated) -- no copies") if world > 1 else "single GPU"},
+        "host": host,
+        "timing": {"value_is": "C-ABI step (HipBackend.step -> stg_step_many) host wall time of one block of `steps` steps between synchronizes",
+                   "api_ms_per_step_is": "the same steps through the public SpinTorqueVecEnv.step() with [N,2] actions",
+                   "retime_rule": "a block is timed again (at most twice) only if the container's cgroup cpu.stat shows nr_throttled "
+                                  "increasing during it (CFS bandwidth throttling of the whole container); never on the measured times",
+                   "gc": "Python collector disabled inside a timed block"},
         "roofline": roofline_step(meas, n_local, args.solver, False, row("headline"), pmc_src),
     }
     if world > 1:
+        out["ranks"] = ranks
         wng = torch.tensor([meas["wall_no_gather_s"]], dtype=torch.float64, device=torch.device("cuda", local_rank))
         dist.all_reduce(wng, op=dist.ReduceOp.MAX)
         out["no_gather"] = {"value": round(n_total * args.steps / float(wng.item()), 1), "unit": "env-steps/s",
@@ -758,7 +867,8 @@ def main():
         dist.all_reduce(gm, op=dist.ReduceOp.MAX)
         out["gather_only"] = {"ms": round(float(gm.item()), 4), "bytes_per_rank": 56 * n_local, "algo": args.gather_algo,
                               "note": "the exchange by itself, back to back with nothing to hide under (max over ranks); in the "
-                                      "timed loop it runs on its own stream under the next step's kernel"}
+                                      "timed loop it runs on its own stream under the next step's kernel",
+                              "all_algos_ms": gather_only_all_algos(n_local, args.solver, args.thermal, args.steps, rank, world, local_rank)}
     if rank == 0 and world == 1 and args.also:
         also = []
         for key, spec in specs[1:]:
@@ -767,28 +877,38 @@ def main():
             if spec["kind"] == "step":
                 also.append({"workload": key, "value": round(spec["n"] * st / m["wall_s"], 1), "unit": "env-steps/s",
                              "ms_per_step": round(m["wall_s"] / st * 1e3, 4),
-                             "roofline": roofline_step(m, spec["n"], spec["solver"], spec["mixed"], row(key), pmc_src)})
+                             "api_ms_per_step": round(m["api_ms_per_step"], 4) if m.get("api_ms_per_step") else None,
+                             "roofline": roofline_step(m, spec["n"], spec["solver"], spec["mixed"], row(key), pmc_src, per_env=spec["per_env"]),
+                             **block_report_of(m)})
             elif spec["kind"] == "short":
                 also.append({"workload": m["workload"], "value": round(m["n"] * m["K"] * st / m["wall_s"], 1), "unit": "env-steps/s",
                              "ms_per_step": round(m["wall_s"] / st / m["K"] * 1e3, 5),
                              "roofline": roofline_hbm(m, m["bytes_per_launch"], row(key), pmc_src,
                                                       {"work_units_per_env_step": round(m["work_units"] / max(m["env_steps"], 1), 2),
-                                                       "noop_frac": round(m["noop_steps"] / max(m["env_steps"], 1), 6)})})
+                                                       "noop_frac": round(m["noop_steps"] / max(m["env_steps"], 1), 6)}),
+                             **block_report_of(m)})
             else:
                 also.append({"workload": m["workload"], "value": round(m["n"] * st / m["wall_s"], 1), "unit": "array-steps/s",
                              "ms_per_step": round(m["wall_s"] / st * 1e3, 4),
                              "roofline": roofline_hbm(m, m["bytes_per_unit"] * m["n"], row(key), pmc_src,
-                                                      {"bytes_per_array_step": m["bytes_per_unit"]})})
+                                                      {"bytes_per_array_step": m["bytes_per_unit"]}),
+                             **block_report_of(m)})
         out["also"] = also
     if rank == 0 and world == 1 and args.cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.solver, args.thermal, args.cpu_seconds)
     elif rank == 0:
         out["cpu_baseline"] = None
+    # the headline's timing record goes LAST (the driver's log keeps the tail of the line)
+    out.update(block_report_of(meas, order=("block_throttled", "block_walls_ms", "blocks_timed")))
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def block_report_of(m, order=("blocks_timed", "block_walls_ms", "block_throttled")):
+    return {k: m[k] for k in order}
 
 
 if __name__ == "__main__":

@@ -275,8 +275,8 @@ struct stg_ctx {
     bool axis_z = false;              // every class has easy axis = +z exactly: the specialised Simple RHS applies
     bool axis_z_llgs = false;         // every class has raw easy axis (0,0,rz) and demag (0,0,Nz): specialised LLGS RHS
     // per-env parameters (stg_set_params_per_env): library-owned copies
-    double* env_soa = nullptr;        // [STG_NPARAM][N]
-    uint8_t *env_type = nullptr, *env_valid = nullptr;
+    double* env_soa = nullptr;        // records [N][ENV_PREC_DOUBLES] (stg_kernels.hpp: EnvParams)
+    uint8_t* env_type = nullptr;      // [N]: the device kind by itself, for the plan kernel (read in env order)
     bool per_env = false;
     int32_t walk_tiles = STG_WALK_TILES_DEFAULT;   // sorted schedule: tiles an XCD group keeps in flight (stg_slot_block)
 };
@@ -293,7 +293,7 @@ static int32_t walk_tiles_from_env() {
 
 static EnvParams env_params_of(const stg_ctx* ctx) {
     EnvParams e{};
-    if (ctx->per_env) { e.soa = ctx->env_soa; e.type = ctx->env_type; e.valid = ctx->env_valid; }
+    if (ctx->per_env) e.soa = ctx->env_soa;
     e.gamma = ctx->cfg.gamma; e.temperature = ctx->cfg.temperature;
     return e;
 }
@@ -413,6 +413,17 @@ int stg_set_params(stg_ctx* ctx, const stg_device_params* table, int32_t n_class
 
 // axis flags of a per-env parameter block: flag[0] = some env's easy axis is not exactly +z after normalisation,
 // flag[1] = some env's raw axis or demag factors have x/y components (LLGS specialisation)
+// rows of the caller's structure of arrays -> the library's per-env records (once per stg_set_params_per_env)
+__global__ void stg_env_pack_kernel(const double* soa, const uint8_t* type, const uint8_t* valid, int64_t N, double* rec) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    double* r = rec + i * ENV_PREC_DOUBLES;
+    for (int k = 0; k < STG_NPARAM; ++k) r[k] = soa[(int64_t)k * N + i];
+    r[STG_NPARAM] = (double)type[i];
+    r[STG_NPARAM + 1] = (double)valid[i];
+    for (int k = STG_NPARAM + 2; k < ENV_PREC_DOUBLES; ++k) r[k] = 0.0;
+}
+
 __global__ void stg_env_axis_kernel(const double* soa, int64_t N, int32_t* flag) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -431,26 +442,26 @@ int stg_set_params_per_env(stg_ctx* ctx, const double* soa_params, const uint8_t
         // both buffers or neither: a context is never left with one of them set
         double* soa = nullptr;
         uint8_t* bytes = nullptr;
-        HIP_TRY(hipMalloc(&soa, sizeof(double) * STG_NPARAM * N));
-        const hipError_t e2 = hipMalloc(&bytes, 2 * N);
+        HIP_TRY(hipMalloc(&soa, sizeof(double) * ENV_PREC_DOUBLES * N));
+        const hipError_t e2 = hipMalloc(&bytes, N);
         if (e2 != hipSuccess) {
             (void)hipFree(soa);
             return fail(STG_E_NOMEM, std::string("hipMalloc(env_type): ") + hipGetErrorString(e2));
         }
         ctx->env_soa = soa;
         ctx->env_type = bytes;
-        ctx->env_valid = bytes + N;
     }
-    HIP_TRY(hipMemcpy(ctx->env_soa, soa_params, sizeof(double) * STG_NPARAM * N, hipMemcpyDeviceToDevice));
+    hipLaunchKernelGGL(stg_env_pack_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, soa_params, dev_type, params_valid,
+                       (int64_t)N, ctx->env_soa);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(ctx->env_type, dev_type, N, hipMemcpyDeviceToDevice));
-    HIP_TRY(hipMemcpy(ctx->env_valid, params_valid, N, hipMemcpyDeviceToDevice));
     // the specialised right-hand sides apply only if EVERY env has the default axis geometry
     int32_t h_flag[2] = {0, 0};
     int32_t* d_flag = nullptr;
     HIP_TRY(hipMalloc(&d_flag, 8));
     hipError_t ef = hipMemset(d_flag, 0, 8);
     if (ef == hipSuccess) {
-        hipLaunchKernelGGL(stg_env_axis_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, ctx->env_soa, (int64_t)N, d_flag);
+        hipLaunchKernelGGL(stg_env_axis_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, soa_params, (int64_t)N, d_flag);
         ef = hipMemcpy(h_flag, d_flag, 8, hipMemcpyDeviceToHost);
     }
     (void)hipFree(d_flag);                                  // on every path

@@ -43,12 +43,16 @@ struct CfgView {
     int32_t max_steps, n_targets, skip_done;
 };
 
-// Per-env parameter block (stg_set_params_per_env): STG_NPARAM rows of N doubles in the field order of
-// stg_device_params, plus the device type and the host-evaluated validity flag per env.
+// Per-env parameters (stg_set_params_per_env): ONE 256-byte record per env, env index major -- the STG_NPARAM doubles of
+// stg_device_params in declaration order, then the device type and the host-evaluated validity flag as doubles.  The
+// caller hands them over as rows of a structure of arrays; the library transposes once.  Rows were the wrong layout for the
+// step kernel for the same reason as for the state: under the duration-sorted schedule a lane's env
+// is anywhere in its tile, so each of its 30 row elements was an 8-byte read out of its own 64-byte request -- measured 1.9
+// KB of HBM traffic per env-step for 242 B of parameters (profiles/r03e: 7.1 x the algorithmic bytes); a record is four
+// whole 64-byte lines whatever the schedule.
+constexpr int ENV_PREC_DOUBLES = 32;
 struct EnvParams {
-    const double* soa;        // [STG_NPARAM][N] or nullptr
-    const uint8_t* type;      // [N]
-    const uint8_t* valid;     // [N]
+    const double* soa;        // records [N][ENV_PREC_DOUBLES] or nullptr (the name is historical: "per-env parameters present")
     double gamma, temperature;
 };
 
@@ -116,9 +120,12 @@ __device__ __forceinline__ void store_state(const StateView& s, int64_t i, const
 }
 
 __device__ __forceinline__ void load_env_params(const EnvParams& e, int64_t N, int64_t i, stg_device_params& p) {
-    const double* q = e.soa + i;
+    double q[ENV_PREC_DOUBLES];
+    const double2* src = reinterpret_cast<const double2*>(e.soa + i * ENV_PREC_DOUBLES);
+#pragma unroll
+    for (int k = 0; k < ENV_PREC_DOUBLES / 2; ++k) { const double2 v = src[k]; q[2 * k] = v.x; q[2 * k + 1] = v.y; }
     int r = 0;
-    auto nx = [&]() { const double v = q[(int64_t)r * N]; ++r; return v; };
+    auto nx = [&]() { const double v = q[r]; ++r; return v; };
     p.damping = nx(); p.ms = nx(); p.ku = nx(); p.volume = nx(); p.polarization = nx();
     for (int k = 0; k < 3; ++k) p.easy_axis[k] = nx();
     for (int k = 0; k < 3; ++k) p.demag[k] = nx();
@@ -128,9 +135,10 @@ __device__ __forceinline__ void load_env_params(const EnvParams& e, int64_t N, i
     for (int k = 0; k < 3; ++k) p.sot_sigma[k] = nx();
     p.vcma_xi = nx(); p.vcma_td = nx(); p.vcma_vbd = nx();
     for (int k = 0; k < 3; ++k) p.shape_demag[k] = nx();
-    p.dev_type = (int32_t)e.type[i];
-    p.params_valid = (int32_t)e.valid[i];
+    p.dev_type = (int32_t)q[STG_NPARAM];
+    p.params_valid = (int32_t)q[STG_NPARAM + 1];
 }
+static_assert(STG_NPARAM + 2 <= ENV_PREC_DOUBLES, "per-env record size");
 
 // Returns this lane's row of derived constants.  One class: the (wave-uniform) global table row, which the compiler
 // turns into scalar loads.  MULTI: the class table staged in LDS, or -- per-env parameters -- a row per lane derived

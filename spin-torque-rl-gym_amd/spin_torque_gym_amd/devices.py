@@ -546,3 +546,24 @@ def per_env_param_block(base: "_lib.StgDeviceParams", n: int, overrides: Dict[st
     valid &= bool(base.params_valid)          # (a base dict that fails the gate, e.g. without 'polarization', stays a no-op)
     dev_type = np.full(n, int(base.dev_type), dtype=np.uint8)
     return block, dev_type, valid.astype(np.uint8)
+
+
+def per_env_param_block_multi(bases, class_index, n: int, overrides: Dict[str, Any]):
+    """As `per_env_param_block` for a mixed batch: env i starts from the flattened record `bases[class_index[i]]` (its device
+    type's own fields -- series resistance, SOT factors, VCMA coefficients -- included), then the per-env `overrides` apply.
+    Returns (block [STG_NPARAM, n], dev_type uint8 [n], valid uint8 [n])."""
+    cls = np.zeros(n, dtype=np.int64) if class_index is None else np.asarray(class_index, dtype=np.int64).reshape(-1)
+    if cls.shape != (n,) or cls.min() < 0 or cls.max() >= len(bases):
+        raise ValueError("class_index must hold one index into the device list per env")
+    if len(bases) == 1:
+        return per_env_param_block(bases[0], n, overrides)
+    parts = [per_env_param_block(b, n, overrides) for b in bases]
+    block = np.empty_like(parts[0][0])
+    dev_type = np.empty(n, dtype=np.uint8)
+    valid = np.empty(n, dtype=np.uint8)
+    for k, (bk, tk, vk) in enumerate(parts):
+        sel = cls == k
+        block[:, sel] = bk[:, sel]
+        dev_type[sel] = tk[sel]
+        valid[sel] = vk[sel]
+    return block, dev_type, valid

@@ -65,6 +65,9 @@ class ShardedSpinTorqueVecEnv:
         self.lo, self.hi = shard_range(self.num_envs, self.world, self.rank)
         self.n_local = self.hi - self.lo
         self._spans = [shard_range(self.num_envs, self.world, r) for r in range(self.world)]
+        # point-to-point operations address their peer by GLOBAL rank (torch.distributed.P2POp), shards are indexed by the
+        # rank inside `group`: the two differ for any group that is not the world
+        self._global = [r if group is None else dist.get_global_rank(group, r) for r in range(self.world)]
         if self.num_envs % self.world and gather_algo == "all_gather":
             # ragged shards: an all-gather needs equal contributions; the point-to-point exchange does not care
             gather_algo = self.gather_algo = "p2p"
@@ -112,8 +115,8 @@ class ShardedSpinTorqueVecEnv:
                 ops = []
                 for peer, (plo, phi) in enumerate(self._spans):
                     if peer != self.rank:
-                        ops.append(dist.P2POp(dist.isend, src, peer, group=self.group))
-                        ops.append(dist.P2POp(dist.irecv, host[plo:phi], peer, group=self.group))
+                        ops.append(dist.P2POp(dist.isend, src, self._global[peer], group=self.group))
+                        ops.append(dist.P2POp(dist.irecv, host[plo:phi], self._global[peer], group=self.group))
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
                 host[self.lo:self.hi] = src
@@ -125,8 +128,8 @@ class ShardedSpinTorqueVecEnv:
             ops = []
             for peer, (plo, phi) in enumerate(self._spans):
                 if peer != self.rank:
-                    ops.append(dist.P2POp(dist.isend, mine, peer, group=self.group))
-                    ops.append(dist.P2POp(dist.irecv, g[plo:phi], peer, group=self.group))
+                    ops.append(dist.P2POp(dist.isend, mine, self._global[peer], group=self.group))
+                    ops.append(dist.P2POp(dist.irecv, g[plo:phi], self._global[peer], group=self.group))
             for w in dist.batch_isend_irecv(ops):
                 w.wait()            # (stream-ordered on NCCL/RCCL: does not block the host)
             return
@@ -239,16 +242,16 @@ class ShardedSpinTorqueVecEnv:
             if tuple(a.shape) != (self.num_envs, 2):
                 raise ValueError(f"expected actions of shape ({self.num_envs}, 2), got {tuple(a.shape)}")
             chunks = [a[plo:phi].contiguous() for plo, phi in self._spans]
-        gsrc = src if self.group is None else dist.get_global_rank(self.group, src)
+        gsrc = self._global[src]
         if self.num_envs % self.world == 0:
             dist.scatter(local, chunks, src=gsrc, group=self.group)
             return local
         # ragged shards: one send per peer (scatter needs equal chunks)
         if self.rank == src:
-            ops = [dist.P2POp(dist.isend, chunks[peer], peer, group=self.group) for peer in range(self.world) if peer != src]
+            ops = [dist.P2POp(dist.isend, chunks[peer], self._global[peer], group=self.group) for peer in range(self.world) if peer != src]
             local.copy_(chunks[src])
         else:
-            ops = [dist.P2POp(dist.irecv, local, src, group=self.group)]
+            ops = [dist.P2POp(dist.irecv, local, gsrc, group=self.group)]
         for w in (dist.batch_isend_irecv(ops) if ops else []):
             w.wait()
         return local

@@ -168,8 +168,8 @@ class SpinTorqueVecEnv:
         self._backend_factory = HipBackend if backend is None else backend
         self._device_index, self.env_id0 = int(device_index), int(env_id0)
         self._class_index, self._per_env_params = class_index, per_env_params
-        if per_env_params and len(self.devices) != 1:
-            raise ValueError("per_env_params needs exactly one base device class")
+        if per_env_params and len(self.devices) > 1 and class_index is None:
+            raise ValueError("per_env_params with several base device classes needs class_index (the base of each env)")
         self.profiler = _TimerTable()
         self.backend = self._make_backend()
         self.single_action_space = _box([-max_current, 0.0], [max_current, max_duration], dtype=np.float32)
@@ -194,10 +194,13 @@ class SpinTorqueVecEnv:
         """One context for (num_envs, cfg, env_id0) with this env's device parameters installed."""
         b = self._backend_factory(self.num_envs, self.cfg, self._device_index, self.env_id0)
         if self._per_env_params:
-            # device-to-device variation: every env gets its own record (one device class as the base); keys are the
-            # reference's device_params keys, values arrays of length num_envs ([num_envs, 3] for vectors)
-            from .devices import per_env_param_block
-            b.set_params_per_env(*per_env_param_block(flatten_params(self.devices[0]), self.num_envs, self._per_env_params))
+            # device-to-device variation: every env gets its own record, starting from its base device class (one class, or
+            # class_index into several -- a mixed STT/SOT/VCMA batch); keys are the reference's device_params keys, values
+            # arrays of length num_envs ([num_envs, 3] for vectors)
+            from .devices import per_env_param_block_multi
+            cls = None if self._class_index is None else torch.as_tensor(self._class_index).cpu().numpy()
+            b.set_params_per_env(*per_env_param_block_multi([flatten_params(d) for d in self.devices], cls, self.num_envs,
+                                                            self._per_env_params))
         else:
             b.set_params([flatten_params(d) for d in self.devices], self._class_index)
         return b

@@ -261,6 +261,44 @@ def test_cfg4_mixed_262144_vs_oracle_slices(stg, torque_model):
         _cmp_slice(hip_r, ora, slice(s0, s0 + SLICE), TOL_RK4, ("cfg4 random classes", torque_model, s0))
 
 
+def test_cfg4_per_env_parameters_262144_vs_oracle_slices(stg):
+    """bench.py's per-env-parameter cfg4 row exactly (run_config(mixed=True, per_env=True)): 262 144 mixed STT/SOT/VCMA envs,
+    every env with its own parameter record (stg_set_params_per_env; SURVEY 8d prices it at 272 B/env-step), built by
+    bench.mixed_kwargs / bench.per_env_variation.  The oracle of a 64-env slice gets the same envs as 64 device classes (one
+    dict per env: its base type's dict with the env's overrides).  Lane sort on/off: identical bits."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    n = 262144
+    m0, tgt, acts = _inputs(n, seed=987, steps=2)
+    mk, cls_t = bench.mixed_kwargs("rk4", n, per_env=True)
+    cls = cls_t.numpy()
+    kw = dict(mk, include_thermal_fluctuations=False, temperature=300.0, solver="rk4", seed=1234, autoreset=True)
+    hip, c = _run_hip(stg, n, m0, tgt, acts, cls=cls, **kw)
+    assert c["env_steps"] == 2 * n and c["noop_steps"] == 0
+    ov = kw["per_env_params"]
+    okw = {k: v for k, v in kw.items() if k not in ("per_env_params", "device_type", "device_params")}
+    worst = 0.0
+    for s0 in _slice_starts(n):
+        types, dicts = [], []
+        for i in range(s0, s0 + SLICE):
+            d = dict(kw["device_params"][cls[i]])
+            for key, arr in ov.items():
+                d[key] = float(arr[i])
+            types.append(kw["device_type"][cls[i]])
+            dicts.append(d)
+        # (the oracle env of the slice: class j = env s0 + j)
+        full_cls = np.zeros(n, dtype=np.uint8)
+        full_cls[s0:s0 + SLICE] = np.arange(SLICE, dtype=np.uint8)
+        ora = _run_oracle_slice(stg, s0, m0, tgt, acts, cls=full_cls, device_type=types, device_params=dicts, **okw)
+        worst = max(worst, _cmp_slice(hip, ora, slice(s0, s0 + SLICE), TOL_RK4, ("cfg4 per-env", s0)))
+    print("cfg4 per-env (262144 mixed, own record per env): worst |dm| vs oracle on slices =", worst)
+    other, c2 = _run_hip(stg, n, m0, tgt, acts, cls=cls, **kw, lane_sort=False)
+    _assert_same_bits(hip, other, "cfg4 per-env lane_sort off")
+    assert c2 == c
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # cfg 2: 4096 envs, T = 0 K, RK45 -- every env
 # ------------------------------------------------------------------------------------------------------------------
