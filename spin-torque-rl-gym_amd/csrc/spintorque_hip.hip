@@ -257,6 +257,16 @@ static int fail(int code, const std::string& msg) {
             return fail(STG_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
     } while (0)
 
+// automatic lane refill of the RK45 step (measured on 262144 ... 1048576 envs): envs per lane = N / 65536
+// (one refill wavefront per SIMD), at most 8 (then two and more per SIMD); below 3 envs per lane the refill launch has nothing
+// over the one-env-per-lane launch with its two wavefronts per SIMD.  Attempts between refill points: 64.
+constexpr int64_t STG_REFILL_AUTO_ENVS = 196608;
+constexpr int32_t STG_REFILL_CHECK_DEFAULT = 64;
+static inline int refill_auto(int64_t n) {
+    if (n < STG_REFILL_AUTO_ENVS) return 0;
+    const int64_t r = n / 65536;
+    return (int)(r > 8 ? 8 : r);
+}
 constexpr int32_t STG_WALK_TILES_DEFAULT = 1 << 20;   // all tiles of the group (fastest, see stg_slot_block)
 
 struct stg_ctx {
@@ -279,6 +289,7 @@ struct stg_ctx {
     uint8_t* env_type = nullptr;      // [N]: the device kind by itself, for the plan kernel (read in env order)
     bool per_env = false;
     int32_t walk_tiles = STG_WALK_TILES_DEFAULT;   // sorted schedule: tiles an XCD group keeps in flight (stg_slot_block)
+    int32_t refill = -1, refill_check = STG_REFILL_CHECK_DEFAULT;        // STG_REFILL experiment override of cfg.lane_refill (-1: none)
 };
 
 static int32_t walk_tiles_from_env() {
@@ -325,6 +336,8 @@ static int check_cfg(const stg_config* c) {
     if (c->solver == STG_SOLVER_RK45 && c->max_attempts < 1) return fail(STG_E_INVALID, "cfg.max_attempts must be >= 1");
     if (c->torque_model < 0 || c->torque_model > 1) return fail(STG_E_INVALID, "cfg.torque_model must be 0 or 1");
     if (c->out_layout != STG_OUT_SOA && c->out_layout != STG_OUT_RECORDS) return fail(STG_E_INVALID, "cfg.out_layout must be STG_OUT_SOA or STG_OUT_RECORDS");
+    if (c->lane_refill < -1 || c->lane_refill == 1 || c->lane_refill > 1024) return fail(STG_E_INVALID, "cfg.lane_refill must be -1 (never), 0 (automatic) or the number of envs per lane (2..1024)");
+    if (c->reserved0 != 0) return fail(STG_E_INVALID, "cfg.reserved0 must be 0");
     if (c->torque_model == 1 && c->solver == STG_SOLVER_RK45)
         return fail(STG_E_INVALID, "the device-physics torque model is implemented for the fixed-step solvers (rk4, euler)");
     return STG_OK;
@@ -350,6 +363,10 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     if (!c) return fail(STG_E_NOMEM, "out of host memory");
     c->device = device_id; c->N = n_envs; c->env_id0 = env_id0; c->cfg = *cfg;
     c->walk_tiles = walk_tiles_from_env();
+    if (const char* e = std::getenv("STG_REFILL")) {
+        int r = 0, chk = 0;
+        if (std::sscanf(e, "%d,%d", &r, &chk) >= 1) { c->refill = r; if (chk > 0) c->refill_check = chk; }
+    }
     // one slab: the state records, the class table, the counter stripes, the lane permutation (each 256-B aligned)
     auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
     const size_t N = (size_t)n_envs;
@@ -554,6 +571,21 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
     // wave_spec: 0 = automatic (thermal launches of at most STG_WAVE_SPEC_MAX_ENVS envs, i.e. latency-bound ones),
     // 1 = always, -1 = never.  Results do not depend on it.
     const bool pc = ctx->cfg.wave_spec > 0 || (ctx->cfg.wave_spec == 0 && ctx->N <= STG_WAVE_SPEC_MAX_ENVS);
+    // lane refill (RK45 throughput launches, see stg_step_refill_kernel).  cfg.lane_refill: 0 = automatic, -1 never, >= 2 forced;
+    // experiment knob STG_REFILL=<envs per lane>[,<attempts between refill points>] overrides the configuration
+    a.refill = 0; a.refill_check = STG_REFILL_CHECK_DEFAULT;
+    if (ctx->cfg.solver == STG_SOLVER_RK45 && K == 1 && !ctx->per_env && !ctx->cfg.skip_done) {
+        int r = ctx->cfg.lane_refill > 0 ? ctx->cfg.lane_refill
+                                         : (ctx->cfg.lane_refill == 0 ? refill_auto(ctx->N) : 0);
+        int chk = STG_REFILL_CHECK_DEFAULT;
+        if (ctx->refill >= 0) { r = ctx->refill; chk = ctx->refill_check; }
+        if (r >= 2 && !(ctx->cfg.thermal && pc)) {
+            a.refill = r; a.refill_check = chk > 0 ? chk : STG_REFILL_CHECK_DEFAULT;
+            stg_dispatch_step_rk45_refill(a, ctx->cfg.thermal != 0, multi, ctx->axis_z_llgs, act_f64, st);
+            HIP_TRY(hipGetLastError());
+            return STG_OK;
+        }
+    }
     switch (ctx->cfg.solver) {
         case STG_SOLVER_RK4: stg_dispatch_step_rk4(a, thermal, multi, ctx->axis_z, devphys, act_f64, pc, st); break;
         case STG_SOLVER_EULER: stg_dispatch_step_euler(a, thermal, multi, ctx->axis_z, devphys, act_f64, pc, st); break;

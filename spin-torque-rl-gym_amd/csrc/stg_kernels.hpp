@@ -69,6 +69,7 @@ struct StepArgs {
     int32_t K, out_every, autoreset;
     int32_t walk;                 // tiles of an XCD group in flight together (sorted schedule, see stg_slot_block)
     int32_t records;              // STG_OUT_RECORDS: `obs` is the record array [K or 1][N][STG_RECORD_BYTES], reward/term/trunc unused
+    int32_t refill, refill_check; // lane-refill launch (stg_step_refill_kernel): envs per lane (rounds), attempts between refill points
     const uint32_t* perm;         // lane -> env (duration-sorted schedule) or nullptr
     unsigned long long* counters; // [4]: env-steps, integrator sub-steps/attempts, RHS evaluations, no-op steps
     float* obs;                   // [K or 1][12][N]
@@ -378,6 +379,90 @@ __device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool
 }
 
 // ------------------------------------------------------------------------------------------------
+// what follows the solve in one env-step (A11-A14): energy, state update, reward, flags, same-step auto-reset, outputs
+// ------------------------------------------------------------------------------------------------
+// m, tgt, etot, step, rng, done: the env's state before the step in, after it out (the caller stores it); so: the solve's result
+// (ignored when !lane_solves: an env that is not stepped -- skip_done, or a lane without an env).
+__device__ __forceinline__ void env_step_tail(const StepArgs& a, int64_t i, int64_t ko, bool wr, bool live, bool lane_solves,
+                                              const double* row, uint64_t env_id, V3& m, V3& tgt, double& etot, int32_t& step,
+                                              uint32_t& rng, bool& done, double J, double T, const SolveOut& so,
+                                              unsigned long long& c_steps, unsigned long long& c_sub, unsigned long long& c_noop) {
+    // the env-step arithmetic around the solver (energy, reward, flags) has no contraction: same roundings in every
+    // instantiation, and the same as NumPy's
+#pragma clang fp contract(off)
+    const int64_t N = a.N;
+    uint8_t st;
+    double reward, energy = 0.0;
+    bool is_success, truncated;
+    if (!lane_solves) {
+        st = STG_STATUS_INACTIVE; reward = 0.0;
+        is_success = dot(m, tgt) >= a.c.thr;
+        truncated = step >= a.c.max_steps;
+    } else {
+        const double prev_align = dot(m, tgt);                                   // spin_torque_env.py:338-339
+        if (fabs(J) > 1e-12) {                                                   // spin_torque_env.py:474-480
+            const V3 ref{row[C_REFX], row[C_REFY], row[C_REFZ]};
+            const double r = resistance(m, (int)row[C_DEVTYPE], row[C_RP], row[C_RAP], row[C_TMR], ref, row[C_RSERIES]);
+            const double v = J * r * row[C_AREA];
+            energy = (v * v) / r * T;
+        }
+        if (so.ok) {                                                             // spin_torque_env.py:461-467
+            const double inv = rsqrt_fast(dot(so.m, so.m));
+            m = V3{so.m.x * inv, so.m.y * inv, so.m.z * inv};
+        }
+        etot += energy;
+        step += 1;
+        rng += 1;
+        const double align = dot(m, tgt);                                        // spin_torque_env.py:350-353
+        is_success = align >= a.c.thr;
+        // default reward (spin_torque_env.py:184-207; rewards/composite_reward.py:65-126), H7 sign kept
+        reward = 10.0 * (is_success ? 10.0 : 0.0);
+        reward += (-a.c.w_energy) * (-energy / 1e-12);
+        reward += (align - prev_align);
+        if (isnan(reward) || isinf(reward)) reward = -1.0;                       // monitoring.py:332-348
+        reward = fmin(fmax(reward, -1e6), 1e6);
+        truncated = step >= a.c.max_steps;                                       // spin_torque_env.py:371-372
+        st = so.ok ? (so.resets > 0 ? STG_STATUS_RESET : STG_STATUS_OK) : STG_STATUS_NOOP;
+        c_steps += 1; c_sub += (unsigned long long)so.work; c_noop += so.ok ? 0 : 1;
+        done = is_success || truncated;
+    }
+    // same-step auto-reset: the finished episode's reward/flags go out with this step, the state is redrawn on the
+    // device and the observation handed to the agent is the NEW episode's first one (the terminal observation goes
+    // to final_obs when the caller asked for it)
+    const bool do_reset = a.autoreset && done && live;
+    if (wr && do_reset && a.final_obs) {
+        if (a.records) {      // env-major float[N][12]: one 48-byte block per env
+            float o[12];
+            make_obs(o, m, tgt, row, a.c, step, etot, J, T);
+            float2* fo = (float2*)(a.final_obs + (ko * N + i) * 12);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) fo[q] = make_float2(o[2 * q], o[2 * q + 1]);
+        } else {
+            write_obs(a.final_obs + ko * 12 * N, N, i, m, tgt, row, a.c, step, etot, J, T);
+        }
+    }
+    if (do_reset) {
+        device_reset_draw(a.c.seed, env_id, rng, a.c, true, true, m, tgt);
+        etot = 0.0; step = 0; done = false;
+        J = 0.0; T = 0.0;                       // last_action = zeros after reset (spin_torque_env.py:283)
+    }
+    if (wr) {
+        if (a.records) {
+            write_record((char*)a.obs + ko * N * STG_RECORD_BYTES, i, m, tgt, row, a.c, step, etot, J, T, (float)reward,
+                         (is_success ? 1u : 0u) | (truncated ? 0x100u : 0u) | ((uint32_t)st << 16));
+        } else {
+            write_obs(a.obs + ko * 12 * N, N, i, m, tgt, row, a.c, step, etot, J, T);
+            a.reward[ko * N + i] = (float)reward;
+            a.term[ko * N + i] = is_success ? 1 : 0;
+            a.trunc[ko * N + i] = truncated ? 1 : 0;
+        }
+        if (a.reward64) a.reward64[ko * N + i] = reward;
+        if (a.energy) a.energy[ko * N + i] = energy;
+        if (a.status) a.status[ko * N + i] = st;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // env.step kernel (A10-A14 around the solver), K fused steps per launch
 // ------------------------------------------------------------------------------------------------
 // Workgroup = WGW integrating wavefronts: 4 (256 envs, one wavefront per SIMD of the CU) for launches that fill the chip,
@@ -469,9 +554,6 @@ __global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR st
         const bool last = (k == a.K - 1);
         const int64_t ko = a.out_every ? k : 0;
         const bool wr = (a.out_every || last) && live;
-        uint8_t st;
-        double reward, energy = 0.0;
-        bool is_success, truncated;
         // with skip_done, finished envs are not integrated: a wavefront whose lanes are all done skips the integrator
         const bool lane_solves = live && !(a.c.skip_done && done);
         const RngKey rk{a.c.seed, env_id, rng};
@@ -492,81 +574,145 @@ __global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR st
                 so = run_solver<SOLVER, THERMAL, false, AXIS_Z, DEVPHYS>(m, J, T, row, a.c, rk, norec, shared, lane_solves);
             }
         }
-        if (!lane_solves) {
-            st = STG_STATUS_INACTIVE; reward = 0.0;
-            is_success = dot(m, tgt) >= a.c.thr;
-            truncated = step >= a.c.max_steps;
-        } else {
-            const double prev_align = dot(m, tgt);                                   // spin_torque_env.py:338-339
-            if (!PC) {
-                InlineNormals inl;
-                so = run_solver<SOLVER, THERMAL, false, AXIS_Z, DEVPHYS>(m, J, T, row, a.c, rk, norec, inl, true);
-            }
-            if (fabs(J) > 1e-12) {                                                   // spin_torque_env.py:474-480
-                const V3 ref{row[C_REFX], row[C_REFY], row[C_REFZ]};
-                const double r = resistance(m, (int)row[C_DEVTYPE], row[C_RP], row[C_RAP], row[C_TMR], ref, row[C_RSERIES]);
-                const double v = J * r * row[C_AREA];
-                energy = (v * v) / r * T;
-            }
-            if (so.ok) {                                                             // spin_torque_env.py:461-467
-                const double inv = rsqrt_fast(dot(so.m, so.m));
-                m = V3{so.m.x * inv, so.m.y * inv, so.m.z * inv};
-            }
-            etot += energy;
-            step += 1;
-            rng += 1;
-            const double align = dot(m, tgt);                                        // spin_torque_env.py:350-353
-            is_success = align >= a.c.thr;
-            // default reward (spin_torque_env.py:184-207; rewards/composite_reward.py:65-126), H7 sign kept
-            reward = 10.0 * (is_success ? 10.0 : 0.0);
-            reward += (-a.c.w_energy) * (-energy / 1e-12);
-            reward += (align - prev_align);
-            if (isnan(reward) || isinf(reward)) reward = -1.0;                       // monitoring.py:332-348
-            reward = fmin(fmax(reward, -1e6), 1e6);
-            truncated = step >= a.c.max_steps;                                       // spin_torque_env.py:371-372
-            st = so.ok ? (so.resets > 0 ? STG_STATUS_RESET : STG_STATUS_OK) : STG_STATUS_NOOP;
-            c_steps += 1; c_sub += (unsigned long long)so.work; c_noop += so.ok ? 0 : 1;
-            done = is_success || truncated;
+        if (!PC && lane_solves) {
+            InlineNormals inl;
+            so = run_solver<SOLVER, THERMAL, false, AXIS_Z, DEVPHYS>(m, J, T, row, a.c, rk, norec, inl, true);
         }
-        // same-step auto-reset: the finished episode's reward/flags go out with this step, the state is redrawn on the
-        // device and the observation handed to the agent is the NEW episode's first one (the terminal observation goes
-        // to final_obs when the caller asked for it)
-        const bool do_reset = a.autoreset && done && live;
-        if (wr && do_reset && a.final_obs) {
-            if (a.records) {      // env-major float[N][12]: one 48-byte block per env
-                float o[12];
-                make_obs(o, m, tgt, row, a.c, step, etot, J, T);
-                float2* fo = (float2*)(a.final_obs + (ko * N + i) * 12);
-#pragma unroll
-                for (int q = 0; q < 6; ++q) fo[q] = make_float2(o[2 * q], o[2 * q + 1]);
-            } else {
-                write_obs(a.final_obs + ko * 12 * N, N, i, m, tgt, row, a.c, step, etot, J, T);
-            }
-        }
-        if (do_reset) {
-            device_reset_draw(a.c.seed, env_id, rng, a.c, true, true, m, tgt);
-            etot = 0.0; step = 0; done = false;
-            J = 0.0; T = 0.0;                       // last_action = zeros after reset (spin_torque_env.py:283)
-        }
-        if (wr) {
-            if (a.records) {
-                write_record((char*)a.obs + ko * N * STG_RECORD_BYTES, i, m, tgt, row, a.c, step, etot, J, T, (float)reward,
-                             (is_success ? 1u : 0u) | (truncated ? 0x100u : 0u) | ((uint32_t)st << 16));
-            } else {
-                write_obs(a.obs + ko * 12 * N, N, i, m, tgt, row, a.c, step, etot, J, T);
-                a.reward[ko * N + i] = (float)reward;
-                a.term[ko * N + i] = is_success ? 1 : 0;
-                a.trunc[ko * N + i] = truncated ? 1 : 0;
-            }
-            if (a.reward64) a.reward64[ko * N + i] = reward;
-            if (a.energy) a.energy[ko * N + i] = energy;
-            if (a.status) a.status[ko * N + i] = st;
-        }
+        env_step_tail(a, i, ko, wr, live, lane_solves, row, env_id, m, tgt, etot, step, rng, done, J, T, so, c_steps, c_sub, c_noop);
     }
     if (live) store_state(a.s, i, m, tgt, etot, step, rng, done);
     // on-device metrics (the reference's EnvironmentMonitor/solver stats are host-side bookkeeping): one atomic per
     // counter per wavefront, into one of COUNTER_STRIPES copies
     wave_add3(a.counters + (size_t)((blockIdx.x * WGW + cw) % COUNTER_STRIPES) * COUNTER_STRIDE, s_cnt + cw * 3, c_steps, c_sub, c_noop);
+}
+
+// ------------------------------------------------------------------------------------------------
+// env.step with LANE REFILL (RK45, one env-step per launch): throughput launches with several envs per lane
+// ------------------------------------------------------------------------------------------------
+// In stg_step_kernel a lane integrates ONE env and then idles until the slowest lane of its wavefront is through: after the
+// duration sort the lanes of a wavefront still differ in attempts (mean/max 0.81: attempts per picosecond vary 1.0-1.9 with
+// nothing known before the solve), and the issue slots of an idle lane are paid all the same.  Here a wavefront owns a QUEUE
+// of R x 64 envs -- R blocks of 64 slots of the sorted schedule -- and a lane that has finished its env writes that env's
+// outputs and takes the next queue entry while its neighbours keep integrating; per-env arithmetic is exactly that of
+// stg_step_kernel (llgs_lane_begin / _attempt / _finish, env_step_tail), so results are bit-identical (tested).
+//  * Queue of wavefront w (of nw = ceil(blocks / R)): round r takes block r * nw + (r odd ? nw - 1 - w : w) of the
+//    rank-major order over the tiles (all tiles' longest block first, ...): boustrophedon, so every wavefront gets the same
+//    total work to within the spread of one block, and inside a wavefront the queue runs from long to short envs (a short
+//    tail at the end).
+//  * A refill point -- finish the env (reload its record, tail of the env-step, stores), take the next entry (state load,
+//    action, the solve's prologue: two RHS calls, initial step) -- is lane-divergent code that the whole wavefront waits
+//    for; it is entered at most every `refill_check` attempts (lanes that finished within that window go together) or when
+//    no lane is integrating.
+// refill_block: 64-slot block `idx` of the rank-major order -> first slot.  Tiles beyond the complete ones: identity.
+__device__ __forceinline__ int64_t refill_slot_base(int64_t idx, int64_t tiles) {
+    if (idx < tiles * TILE_WAVES) {
+        const int64_t j = idx / tiles, t = idx - j * tiles;
+        return t * TILE_ENVS + j * 64;
+    }
+    return idx * 64;
+}
+
+template <bool THERMAL, bool MULTI, bool AXIS_Z, typename AT, int WGW>
+__global__ void __launch_bounds__(WGW * 64) stg_step_refill_kernel(const StepArgs a) {
+    extern __shared__ double s_tab[];
+    __shared__ unsigned long long s_cnt[WGW * 3];
+    const int lane = (int)(threadIdx.x & 63u);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (MULTI) {       // class table -> LDS (per-env parameter records do not take this kernel)
+        for (int j = threadIdx.x; j < a.ncls * C_COUNT; j += blockDim.x) s_tab[j] = a.ctab[j];
+        __syncthreads();
+    }
+    const int64_t N = a.N;
+    const int R = a.refill;
+    const int64_t nblk = (N + 63) / 64, nw = (nblk + R - 1) / R, tiles = a.perm ? N / TILE_ENVS : 0;
+    const int64_t w = (int64_t)blockIdx.x * WGW + wave;
+    if (w >= nw) return;
+    const AT* act = (const AT*)a.actions;
+    const Recorder norec{};
+    const LlgsEnergyK noek{};
+    const Dp5Tab tb = make_dp5_tab();
+    InlineNormals ns;
+    unsigned long long c_steps = 0, c_sub = 0, c_noop = 0;
+
+    // the lane's env in flight
+    int64_t i = 0;
+    bool has_env = false;
+    double J = 0.0, T = 0.0;
+    const double* row = a.ctab;
+    LlgsK k = load_llgs(row);
+    LlgsLane L;
+    L.active = false; L.ok = true; L.rejected = false; L.attempts = 0; L.npts = 0;
+    L.y = L.f = L.m0 = V3{0.0, 0.0, 1.0};
+    L.t = L.T = L.h_abs = L.min_step = L.bJ = L.bpJ = 0.0;
+    V3 out_m{0.0, 0.0, 1.0};
+
+    // takes queue entry p (if there is one): state, action, the solve's prologue
+    auto take = [&](int p, bool want) {
+        const int r = p >> 6;
+        const int64_t idx = (int64_t)r * nw + ((r & 1) ? (nw - 1 - w) : w);
+        const int64_t slot = refill_slot_base(idx, tiles) + (p & 63);
+        const bool valid = want && r < R && idx < nblk && slot < N;
+        if (!valid) return;
+        i = a.perm ? (int64_t)a.perm[slot] : slot;
+        V3 m, tgt;
+        double etot;
+        int32_t step;
+        uint32_t rng;
+        bool done;
+        load_state(a.s, i, m, tgt, etot, step, rng, done);
+        parse_action<AT>(act[i], act[N + i], a.c.max_current, a.c.max_duration, J, T);
+        if (MULTI) {
+            const int c = (int)a.cls[i];
+            row = s_tab + (c < a.ncls ? c : 0) * C_COUNT;
+            k = load_llgs(row);
+        }
+        const RngKey rk{a.c.seed, (uint64_t)(a.env_id0 + i), rng};
+        llgs_lane_begin<THERMAL, false, AXIS_Z>(L, out_m, m, J, T, k, row[C_BETA], row[C_BETAP], a.c.rtol, a.c.atol, a.c.max_step, rk,
+                                                norec, noek, ns, true);
+        has_env = true;
+    };
+    // finishes the lane's env: the rest of the env-step after the solve, outputs, state
+    auto finish = [&]() {
+        const SolveOut so = llgs_lane_finish<false>(L, out_m, norec, noek, ns);
+        V3 m, tgt;
+        double etot;
+        int32_t step;
+        uint32_t rng;
+        bool done;
+        load_state(a.s, i, m, tgt, etot, step, rng, done);      // (m is the row the solve started from: L.m0)
+        env_step_tail(a, i, 0, true, true, true, row, (uint64_t)(a.env_id0 + i), m, tgt, etot, step, rng, done, J, T, so, c_steps, c_sub, c_noop);
+        store_state(a.s, i, m, tgt, etot, step, rng, done);
+        has_env = false;
+        L.active = false;
+    };
+
+    WaveProf prof;
+    prof.start();
+    take(lane, true);
+    int q_next = 64;                                            // wave-uniform: the next queue entry to hand out
+    const int q_len = R * 64;
+    const int check = a.refill_check > 0 ? a.refill_check : 1;
+    for (;;) {
+        // up to `check` attempts of the whole wavefront (lanes that are through walk along, frozen) ...
+        for (int c = 0; c < check; ++c) {
+            llgs_lane_gate(L, a.c.max_attempts);
+            if (__ballot(L.active) == 0ull) break;
+            V3 z2{0.0, 0.0, 0.0}, z3{0.0, 0.0, 0.0};
+            llgs_lane_attempt<THERMAL, false, AXIS_Z>(L, out_m, k, tb, a.c.rtol, a.c.atol, a.c.max_step, norec, noek, ns, z2, z3);
+        }
+        // ... then a refill point: finished lanes write their env and take entries q_next, q_next + 1, ... in lane order
+        const bool fin = has_env && !L.active;
+        const unsigned long long finished = __ballot(fin);
+        if (finished != 0ull) {
+            if (fin) finish();
+            const int rank = (int)__builtin_popcountll(finished & ((1ull << lane) - 1ull));
+            take(q_next + rank, fin && q_next + rank < q_len);
+            q_next += (int)__builtin_popcountll(finished);
+        }
+        if (__ballot(has_env) == 0ull) break;
+    }
+    prof.stop(L.attempts);
+    wave_add3(a.counters + (size_t)((blockIdx.x * WGW + wave) % COUNTER_STRIPES) * COUNTER_STRIDE, s_cnt + wave * 3, c_steps, c_sub, c_noop);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -624,7 +770,28 @@ static void dispatch_step(const StepArgs& a, bool thermal, bool multi, bool axis
     }
 }
 
+// lane-refill launch of the RK45 step (a.refill = envs per lane >= 2): ceil(ceil(N / 64) / refill) wavefronts
+template <bool THERMAL, bool MULTI, bool AXIS_Z>
+static void launch_refill(const StepArgs& a, int act_f64, hipStream_t st) {
+    constexpr int WGW = 4;
+    const int64_t nblk = (a.N + 63) / 64, nw = (nblk + a.refill - 1) / a.refill;
+    const dim3 grid((unsigned)((nw + WGW - 1) / WGW));
+    const size_t lds = MULTI ? (size_t)a.ncls * C_COUNT * sizeof(double) : 0;
+    if (act_f64) hipLaunchKernelGGL((stg_step_refill_kernel<THERMAL, MULTI, AXIS_Z, double, WGW>), grid, dim3(WGW * 64), lds, st, a);
+    else hipLaunchKernelGGL((stg_step_refill_kernel<THERMAL, MULTI, AXIS_Z, float, WGW>), grid, dim3(WGW * 64), lds, st, a);
+}
+static void dispatch_refill(const StepArgs& a, bool thermal, bool multi, bool axis_z, int act_f64, hipStream_t st) {
+    if (thermal) {
+        if (multi) { if (axis_z) launch_refill<true, true, true>(a, act_f64, st); else launch_refill<true, true, false>(a, act_f64, st); }
+        else { if (axis_z) launch_refill<true, false, true>(a, act_f64, st); else launch_refill<true, false, false>(a, act_f64, st); }
+    } else {
+        if (multi) { if (axis_z) launch_refill<false, true, true>(a, act_f64, st); else launch_refill<false, true, false>(a, act_f64, st); }
+        else { if (axis_z) launch_refill<false, false, true>(a, act_f64, st); else launch_refill<false, false, false>(a, act_f64, st); }
+    }
+}
+
 // defined in stg_step_{rk4,euler,rk45}.hip
 void stg_dispatch_step_rk4(const StepArgs& a, bool thermal, bool multi, bool axis_z, bool devphys, int act_f64, bool pc, hipStream_t st);
 void stg_dispatch_step_euler(const StepArgs& a, bool thermal, bool multi, bool axis_z, bool devphys, int act_f64, bool pc, hipStream_t st);
 void stg_dispatch_step_rk45(const StepArgs& a, bool thermal, bool multi, bool axis_z, int act_f64, bool pc, hipStream_t st);
+void stg_dispatch_step_rk45_refill(const StepArgs& a, bool thermal, bool multi, bool axis_z, int act_f64, hipStream_t st);

@@ -338,9 +338,6 @@ struct SharedNormalsT {
     const T* buf;           // this workgroup's LDS ring [DEPTH][SHARED_CHUNK_MAX][64]
     int* hs;                // LDS: the handshake words / BARRIER: the integrator's "continues" flag, two alternating copies
     int lane, it, idx, seen;   // seen: the producer's count as last read (a lane-uniform value in a VGPR)
-#ifdef STG_PROFILE_LOOP
-    int waited = 0, polls = 0;
-#endif
     bool broken;               // the poll budget ran out (never, unless the protocol is broken): the solve reports failure
     __device__ __forceinline__ void begin(const RngKey&) { it = 0; idx = 0; seen = 1; broken = false; }    // chunk 0 is there (H2)
     __device__ __forceinline__ V3 draw(bool) {
@@ -370,16 +367,10 @@ struct SharedNormalsT {
         int have = __builtin_amdgcn_readfirstlane(seen);
         if (__builtin_expect(mine && have <= it, 0)) {
             int spins = 0;
-#ifdef STG_PROFILE_LOOP
-            ++waited;
-#endif
 #pragma unroll 1
             do {
                 if (spins) __builtin_amdgcn_s_sleep(1);
                 have = pc_load(hs);
-#ifdef STG_PROFILE_LOOP
-                ++polls;
-#endif
             } while (have <= it && ++spins <= PC_SPIN_CAP);
             broken = broken || have <= it;
         }
@@ -797,80 +788,125 @@ __device__ __forceinline__ double llgs_torque_norms(const V3& m, double bJ, doub
 
 __device__ __forceinline__ double rms3(const V3& a) { return sqrt(dot(a, a)) / 1.7320508075688772; }   // common.py:63-65
 
-// A7 (+A8 when RECORD): scipy solve_ivp(RK45) as LLGSSolver.solve drives it.
 #ifdef STG_PROFILE_LOOP
-// experiment builds only (-DSTG_PROFILE_LOOP): cycles spent in the segments of the RK45 attempt, summed over the attempts
-// of wavefront 0 of workgroup 0, read back with stg_debug_prof()
-static __device__ long long g_stg_prof[16];   // (one copy per translation unit; stg_debug_prof reads the RK45 unit's)
-// per integrating wavefront (first STG_PROF_WAVES workgroups x 4): start/end s_memtime, start/end s_memrealtime (100 MHz),
-// HW_ID, attempts -- where each wavefront ran, for how long, and at which shader clock
+// experiment builds only (-DSTG_PROFILE_LOOP): per integrating wavefront (first STG_PROF_WAVES of the launch) start/end
+// s_memtime, start/end s_memrealtime (100 MHz), HW_ID, attempts of its worst lane -- where each wavefront ran, for how long,
+// and at which shader clock; read back with stg_debug_waves() (tools/probe_wave_records.py)
 #define STG_PROF_WAVES 8192
 static __device__ long long g_stg_wave[STG_PROF_WAVES * 6];
-#define STG_TICK(k) do { const long long now_ = __builtin_readcyclecounter(); prof_[k] += now_ - last_; last_ = now_; } while (0)
+struct WaveProf {
+    long long t0, r0;
+    __device__ __forceinline__ void start() { t0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    __device__ __forceinline__ void stop(long long attempts) {
+        const int wid_ = blockIdx.x * ((int)blockDim.x / 64) + (int)threadIdx.x / 64;
+        long long att_max_ = attempts;
+        for (int o_ = 32; o_ > 0; o_ >>= 1) { const long long v_ = __shfl_xor(att_max_, o_); att_max_ = v_ > att_max_ ? v_ : att_max_; }
+        if ((threadIdx.x & 63) == 0 && wid_ < STG_PROF_WAVES) {
+            long long* r_ = g_stg_wave + 6 * wid_;
+            r_[0] = t0; r_[1] = __builtin_readcyclecounter(); r_[2] = r0; r_[3] = __builtin_amdgcn_s_memrealtime();
+            r_[4] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11))      // HW_REG_HW_ID, 32 bits
+                    | ((long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32);    // HW_REG_XCC_ID
+            r_[5] = att_max_;
+        }
+    }
+};
 #else
-#define STG_TICK(k) do { } while (0)
+struct WaveProf {
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void stop(long long) {}
+};
 #endif
 
-template <bool THERMAL, bool RECORD, bool AXIS_Z, class NSRC>
-__device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T, const LlgsK& k, double beta,
-                                               double betap, double rtol, double atol, double max_step,
-                                               int64_t max_attempts, const RngKey& rk, const Recorder& rec,
-                                               const LlgsEnergyK& ek, NSRC& ns, bool enabled) {
-    // Dormand-Prince tableau (rk.py:380-391)
-    // The 25 tableau constants do not fit next to everything else that is wave-uniform: with all of them in SGPR pairs the
-    // kernel sits at the SGPR limit and the compiler re-materialises 15-21 halves per attempt inside the loop (s_mov_b32:
-    // one issue slot each for a lone wavefront).  The rows used once per attempt live in VGPRs instead (opaque to the
-    // optimiser, set once before the loop; same doubles): 439 -> 420 instructions per attempt at T = 0 K, 504 -> 492 for the
-    // wave-specialised thermal kernel; measured 1.555 -> 1.475 ms at 4096 envs, 2.16 -> 2.11 ms on the headline launch.
-#define STG_TABV(name, val) const double name = vgpr_const(val)
-    constexpr double A21 = 1.0 / 5;
-    constexpr double A31 = 3.0 / 40, A32 = 9.0 / 40;
-    constexpr double A41 = 44.0 / 45, A42 = -56.0 / 15, A43 = 32.0 / 9;
-    STG_TABV(A51, 19372.0 / 6561); STG_TABV(A52, -25360.0 / 2187); STG_TABV(A53, 64448.0 / 6561); STG_TABV(A54, -212.0 / 729);
-    STG_TABV(A61, 9017.0 / 3168); STG_TABV(A62, -355.0 / 33); STG_TABV(A63, 46732.0 / 5247); STG_TABV(A64, 49.0 / 176); STG_TABV(A65, -5103.0 / 18656);
-    constexpr double B1 = 35.0 / 384, B3 = 500.0 / 1113, B4 = 125.0 / 192, B5 = -2187.0 / 6784, B6 = 11.0 / 84;
-    STG_TABV(E1, -71.0 / 57600); STG_TABV(E3, 71.0 / 16695); STG_TABV(E4, -71.0 / 1920); STG_TABV(E5, 17253.0 / 339200); STG_TABV(E6, -22.0 / 525); STG_TABV(E7, 1.0 / 40);
-#undef STG_TABV
-    // (stage nodes C = 1/5, 3/10, 4/5, 8/9, 1, 1: the RHS is autonomous but for the pulse gate, see `fun`)
+// The solve is split into begin / attempt / finish on a per-lane state (LlgsLane), so that the same arithmetic serves the
+// one-env-per-lane loop (llgs_solve) and the lane-refill step kernel (stg_kernels.hpp: stg_step_refill_kernel), in which a
+// lane that has finished its env takes the next one of its wavefront's queue while its neighbours keep integrating.
+//
+// Dormand-Prince tableau (rk.py:380-391).  The 25 tableau constants do not fit next to everything else that is wave-uniform:
+// with all of them in SGPR pairs the kernel sits at the SGPR limit and the compiler re-materialises 15-21 halves per attempt
+// inside the loop (s_mov_b32: one issue slot each for a lone wavefront).  The rows used once per attempt live in VGPRs instead
+// (opaque to the optimiser, set once before the loop; same doubles): 439 -> 420 instructions per attempt at T = 0 K, 504 -> 492
+// for the wave-specialised thermal kernel; measured 1.555 -> 1.475 ms at 4096 envs, 2.16 -> 2.11 ms on the headline launch.
+// (stage nodes C = 1/5, 3/10, 4/5, 8/9, 1, 1: the RHS is autonomous but for the pulse gate, see llgs_lane_attempt)
+struct Dp5Tab {
+    double A51, A52, A53, A54, A61, A62, A63, A64, A65, E1, E3, E4, E5, E6, E7;
+};
+__device__ __forceinline__ Dp5Tab make_dp5_tab() {
+    Dp5Tab t;
+    t.A51 = vgpr_const(19372.0 / 6561); t.A52 = vgpr_const(-25360.0 / 2187); t.A53 = vgpr_const(64448.0 / 6561); t.A54 = vgpr_const(-212.0 / 729);
+    t.A61 = vgpr_const(9017.0 / 3168); t.A62 = vgpr_const(-355.0 / 33); t.A63 = vgpr_const(46732.0 / 5247); t.A64 = vgpr_const(49.0 / 176);
+    t.A65 = vgpr_const(-5103.0 / 18656);
+    t.E1 = vgpr_const(-71.0 / 57600); t.E3 = vgpr_const(71.0 / 16695); t.E4 = vgpr_const(-71.0 / 1920); t.E5 = vgpr_const(17253.0 / 339200);
+    t.E6 = vgpr_const(-22.0 / 525); t.E7 = vgpr_const(1.0 / 40);
+    return t;
+}
 
-    SolveOut o{m0, 0, 0, 0, false};
+// one lane's solve in flight
+struct LlgsLane {
+    V3 y, f;                 // state and f(y) (FSAL)
+    V3 m0;                   // the input row (returned when the solve fails)
+    double t, T, h_abs, min_step;
+    double bJ, bpJ;          // beta J, beta' J (0 when |J| < 1e-12)
+    int64_t attempts;
+    int32_t npts;
+    bool ok, rejected, active;
+};
+
+__device__ __forceinline__ double llgs_min_step_at(double tt) {   // 10 * |nextafter(t, inf) - t|, t >= 0                      rk.py:119
+    return 10.0 * (__longlong_as_double(__double_as_longlong(tt) + 1) - tt);
+}
+
+// every accepted point is renormalised on output (llgs_solver.py:152-153); without a recorder only the last one is ever
+// read, so it is formed once after the loop (llgs_lane_finish)
+template <bool RECORD>
+__device__ __forceinline__ void llgs_lane_emit(LlgsLane& L, V3& out_m, const Recorder& rec, const LlgsEnergyK& ek) {
+    const double inv = rsqrt_fast(dot(L.y, L.y));
+    out_m = V3{L.y.x * inv, L.y.y * inv, L.y.z * inv};
+    // (the recorded time points never pass T, so current_func(t) = J at every one of them)
+    if (RECORD) rec.put(L.npts, L.t, out_m, rec.e ? llgs_energy(out_m, ek) : 0.0, rec.tq ? llgs_torque_norms(out_m, L.bJ, L.bpJ) : 0.0);
+    ++L.npts;
+}
+
+// RHS call; the pulse gate of spin_torque_env.py:442-443 (J while t <= T) can only close for stage times of the form
+// fl(t + h) on the step that is clamped to end at T: every other stage time is fl(t + fl(c h)) with c <= 8/9, hence
+// <= t_new <= T by monotonic rounding, and an unclamped fl(t + h) is within an ulp of t_new < T.  So only k6 / f_new of an
+// attempt test the gate (`on`).
+template <bool THERMAL, bool AXIS_Z>
+__device__ __forceinline__ V3 llgs_fun(const LlgsLane& L, const LlgsK& k, const V3& y, const V3& ht, bool on) {
+    return llgs_rhs<THERMAL, AXIS_Z>(y, k, on ? L.bJ : 0.0, on ? L.bpJ : 0.0, ht);
+}
+// the thermal field of one RHS call (already times -gamma); EVEN selects the normal-stream phase (calls alternate).  Fetch and
+// evaluation are separate so that a loop can fetch call j+1's field before it evaluates call j: with the shared source a
+// draw is three LDS reads, and issued at the point of use each of them stalls the lone integrating wavefront for the LDS
+// latency (six stalls per attempt).
+template <bool THERMAL, class NSRC>
+__device__ __forceinline__ V3 llgs_draw(NSRC& ns, const LlgsK& k, bool even) {
+    if (!THERMAL) return V3{0.0, 0.0, 0.0};
+    return NSRC::kScaled ? ns.draw(even) : scale3(k.ghs, ns.draw(even));
+}
+
+// Prologue of a solve: normalise m0 (llgs_solver.py:76), f(t0, y0), select_initial_step (common.py:68-134).
+// `enabled` = false: a lane that only walks its workgroup's chunk loop (SharedNormals).
+template <bool THERMAL, bool RECORD, bool AXIS_Z, class NSRC>
+__device__ __forceinline__ void llgs_lane_begin(LlgsLane& L, V3& out_m, const V3& m0, double J, double T, const LlgsK& k, double beta,
+                                                double betap, double rtol, double atol, double max_step, const RngKey& rk,
+                                                const Recorder& rec, const LlgsEnergyK& ek, NSRC& ns, bool enabled) {
     const bool useJ = !(fabs(J) < 1e-12);                                   // llgs_solver.py:222
-    const double bJ = useJ ? beta * J : 0.0, bpJ = useJ ? betap * J : 0.0;
-    const V3 zero{0.0, 0.0, 0.0};
+    L.bJ = useJ ? beta * J : 0.0;
+    L.bpJ = useJ ? betap * J : 0.0;
+    L.m0 = m0;
+    L.T = T;
     if (THERMAL) ns.begin(rk);
-    // RHS call; EVEN selects the normal-stream phase (calls alternate).  The pulse gate of spin_torque_env.py:442-443
-    // (J while t <= T) can only close for stage times of the form fl(t + h) on the step that is clamped to end at T:
-    // every other stage time is fl(t + fl(c h)) with c <= 8/9, hence <= t_new <= T by monotonic rounding, and an
-    // unclamped fl(t + h) is within an ulp of t_new < T.  So only k6 / f_new of an attempt test the gate (`on`).
-    // `draw` fetches the thermal field of one RHS call (already times -gamma), `fun` evaluates the call.  They are
-    // separate so that the loop can fetch call j+1's field before it evaluates call j: with the shared source a draw
-    // is three LDS reads, and issued at the point of use each of them stalls the lone integrating wavefront for the
-    // LDS latency (six stalls per attempt).
-    auto draw = [&](bool even) -> V3 {
-        if (!THERMAL) return zero;
-        return NSRC::kScaled ? ns.draw(even) : scale3(k.ghs, ns.draw(even));
-    };
-    auto fun = [&](const V3& y, const V3& ht, bool on) -> V3 {
-        return llgs_rhs<THERMAL, AXIS_Z>(y, k, on ? bJ : 0.0, on ? bpJ : 0.0, ht);
-    };
     const double n0 = rsqrt_fast(dot(m0, m0));                              // llgs_solver.py:76
-    V3 y{m0.x * n0, m0.y * n0, m0.z * n0};
-    double t = 0.0;
-    int32_t npts = 0;
-    // every accepted point is renormalised on output (llgs_solver.py:152-153); without a recorder only the last one is
-    // ever read, so it is formed once after the loop
-    auto emit = [&]() {
-        const double inv = rsqrt_fast(dot(y, y));
-        o.m = V3{y.x * inv, y.y * inv, y.z * inv};
-        // (the recorded time points never pass T, so current_func(t) = J at every one of them)
-        if (RECORD) rec.put(npts, t, o.m, rec.e ? llgs_energy(o.m, ek) : 0.0, rec.tq ? llgs_torque_norms(o.m, bJ, bpJ) : 0.0);
-        ++npts;
-    };
-    if (RECORD) emit(); else ++npts;
-    V3 f = fun(y, draw(true), true);                       // t = 0 <= T
+    L.y = V3{m0.x * n0, m0.y * n0, m0.z * n0};
+    L.t = 0.0;
+    L.npts = 0;
+    if (RECORD) llgs_lane_emit<RECORD>(L, out_m, rec, ek); else ++L.npts;
+    L.f = llgs_fun<THERMAL, AXIS_Z>(L, k, L.y, llgs_draw<THERMAL>(ns, k, true), true);        // t = 0 <= T
     double h_abs;
     {   // select_initial_step (common.py:68-134), order = error_estimator_order = 4
         // (quotients by reciprocal-multiply, ~1 ulp: these norms only seed the first step size)
+        const V3& y = L.y;
+        const V3& f = L.f;
         const V3 sc{atol + fabs(y.x) * rtol, atol + fabs(y.y) * rtol, atol + fabs(y.z) * rtol};
         const V3 isc{rcp_fast(sc.x), rcp_fast(sc.y), rcp_fast(sc.z)};
         const double d0 = rms3(V3{y.x * isc.x, y.y * isc.y, y.z * isc.z});
@@ -878,143 +914,157 @@ __device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T,
         double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : (0.01 * d0) * rcp_fast(d1);
         h0 = fmin(h0, T);
         const V3 y1{y.x + h0 * f.x, y.y + h0 * f.y, y.z + h0 * f.z};
-        const V3 f1 = fun(y1, draw(false), true);          // t + h0 = h0 <= T (h0 = min(h0, T))
+        const V3 f1 = llgs_fun<THERMAL, AXIS_Z>(L, k, y1, llgs_draw<THERMAL>(ns, k, false), true);   // t + h0 = h0 <= T (h0 = min(h0, T))
         const double d2 = rms3(V3{(f1.x - f.x) * isc.x, (f1.y - f.y) * isc.y, (f1.z - f.z) * isc.z}) * rcp_fast(h0);
         const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : fifth_root(0.01 * rcp_fast(fmax(d1, d2)));
         h_abs = fmin(fmin(100.0 * h0, h1), fmin(T, max_step));
     }
-    // SciPy nests "while not finished: step()" around "while not step_accepted: attempt" (ivp.py:654-661, base.py:175-206,
-    // rk.py:111-181).  Here ONE flat loop runs one attempt per iteration and an accepted attempt performs the outer
-    // loop's bookkeeping itself: same sequence of attempts per lane, but a wavefront needs max-over-lanes(total attempts)
-    // iterations instead of sum-over-steps(max-over-lanes(attempts of that step)).
-    auto min_step_at = [](double tt) {   // 10 * |nextafter(t, inf) - t|, t >= 0                      rk.py:119
-        return 10.0 * (__longlong_as_double(__double_as_longlong(tt) + 1) - tt);
-    };
-    bool ok = true, rejected = false;
-    int64_t attempts = 0;
-    double min_step = min_step_at(t);
-    h_abs = h_abs > max_step ? max_step : (h_abs < min_step ? min_step : h_abs);          // rk.py:121-126
+    L.ok = true;
+    L.rejected = false;
+    L.attempts = 0;
+    L.min_step = llgs_min_step_at(L.t);
+    L.h_abs = h_abs > max_step ? max_step : (h_abs < L.min_step ? L.min_step : h_abs);          // rk.py:121-126
+    L.active = enabled && (L.t != T);       // (a disabled lane only walks the workgroup's chunk loop)
+}
+
+// The budget / minimum-step test that opens an attempt (rk.py:132-133 + the attempt budget); a lane that fails it stops.
+__device__ __forceinline__ void llgs_lane_gate(LlgsLane& L, int64_t max_attempts) {
+    // (bitwise on purpose: no short-circuit control flow inside the wave-uniform attempt loop)
+    const bool fail_now = L.active & ((L.h_abs < L.min_step) | (L.attempts >= max_attempts));
+    L.ok = L.ok & !fail_now;
+    L.active = L.active & !fail_now;
+}
+
+// ONE attempted step (rk.py:111-181) of a lane; the body has no lane-divergent control flow: a lane that is through (or
+// never started) walks along with its state frozen by the selects below.  SciPy nests "while not finished: step()" around
+// "while not step_accepted: attempt" (ivp.py:654-661, base.py:175-206); here an accepted attempt performs the outer loop's
+// bookkeeping itself: same sequence of attempts per lane, but a wavefront needs max-over-lanes(total attempts) iterations
+// instead of sum-over-steps(max-over-lanes(attempts of that step)).
+// z2, z3: the thermal fields of the first two RHS calls of the attempt (fetched by the caller, see llgs_draw).
+template <bool THERMAL, bool RECORD, bool AXIS_Z, class NSRC>
+__device__ __forceinline__ void llgs_lane_attempt(LlgsLane& L, V3& out_m, const LlgsK& k, const Dp5Tab& tb, double rtol, double atol,
+                                                  double max_step, const Recorder& rec, const LlgsEnergyK& ek, NSRC& ns, V3 z2, V3 z3) {
+    constexpr double A21 = 1.0 / 5;
+    constexpr double A31 = 3.0 / 40, A32 = 9.0 / 40;
+    constexpr double A41 = 44.0 / 45, A42 = -56.0 / 15, A43 = 32.0 / 9;
+    constexpr double B1 = 35.0 / 384, B3 = 500.0 / 1113, B4 = 125.0 / 192, B5 = -2187.0 / 6784, B6 = 11.0 / 84;
+    const double A51 = tb.A51, A52 = tb.A52, A53 = tb.A53, A54 = tb.A54, A61 = tb.A61, A62 = tb.A62, A63 = tb.A63, A64 = tb.A64, A65 = tb.A65;
+    const double E1 = tb.E1, E3 = tb.E3, E4 = tb.E4, E5 = tb.E5, E6 = tb.E6, E7 = tb.E7;
+    const double T = L.T;
+    const bool active = L.active;
+    const V3 y = L.y;
+    const double t = L.t;
+    auto fun = [&](const V3& yy, const V3& ht, bool on) -> V3 { return llgs_fun<THERMAL, AXIS_Z>(L, k, yy, ht, on); };
+    auto draw = [&](bool even) -> V3 { return llgs_draw<THERMAL>(ns, k, even); };
+    L.attempts += active ? 1 : 0;
+    double t_new = add_x(t, L.h_abs);
+    if (t_new - T > 0.0) t_new = T;
+    const double h = sub_x(t_new, t);
+    const double h_try = fabs(h);
+    // rk_step (rk.py:14-70); the one stage time that can pass T is formed without contraction
+    const bool on_end = add_x(t, h) <= T;
+    const V3 k1 = L.f;
+    // normal-stream phases alternate per call (k2: even, k3: odd, ...); each field is fetched one call ahead
+    if (THERMAL && !NSRC::kShared) { z2 = draw(true); z3 = draw(false); }
+    const V3 k2 = fun(V3{y.x + (k1.x * A21) * h, y.y + (k1.y * A21) * h, y.z + (k1.z * A21) * h}, z2, true);
+    const V3 z4 = draw(true);
+    const V3 k3 = fun(V3{y.x + (k1.x * A31 + k2.x * A32) * h, y.y + (k1.y * A31 + k2.y * A32) * h,
+                         y.z + (k1.z * A31 + k2.z * A32) * h}, z3, true);
+    const V3 z5 = draw(false);
+    const V3 k4 = fun(V3{y.x + (k1.x * A41 + k2.x * A42 + k3.x * A43) * h, y.y + (k1.y * A41 + k2.y * A42 + k3.y * A43) * h,
+                         y.z + (k1.z * A41 + k2.z * A42 + k3.z * A43) * h}, z4, true);
+    const V3 z6 = draw(true);
+    const V3 k5 = fun(V3{y.x + (k1.x * A51 + k2.x * A52 + k3.x * A53 + k4.x * A54) * h,
+                         y.y + (k1.y * A51 + k2.y * A52 + k3.y * A53 + k4.y * A54) * h,
+                         y.z + (k1.z * A51 + k2.z * A52 + k3.z * A53 + k4.z * A54) * h}, z5, true);
+    if (THERMAL) ns.peek();
+    const V3 z7 = draw(false);
+    const V3 k6 = fun(V3{y.x + (k1.x * A61 + k2.x * A62 + k3.x * A63 + k4.x * A64 + k5.x * A65) * h,
+                         y.y + (k1.y * A61 + k2.y * A62 + k3.y * A63 + k4.y * A64 + k5.y * A65) * h,
+                         y.z + (k1.z * A61 + k2.z * A62 + k3.z * A63 + k4.z * A64 + k5.z * A65) * h}, z6, on_end);
+    const V3 y_new{y.x + h * (k1.x * B1 + k3.x * B3 + k4.x * B4 + k5.x * B5 + k6.x * B6),
+                   y.y + h * (k1.y * B1 + k3.y * B3 + k4.y * B4 + k5.y * B5 + k6.y * B6),
+                   y.z + h * (k1.z * B1 + k3.z * B3 + k4.z * B4 + k5.z * B5 + k6.z * B6)};
+    const V3 f_new = fun(y_new, z7, on_end);
+    const V3 ev{(k1.x * E1 + k3.x * E3 + k4.x * E4 + k5.x * E5 + k6.x * E6 + f_new.x * E7) * h,
+                (k1.y * E1 + k3.y * E3 + k4.y * E4 + k5.y * E5 + k6.y * E6 + f_new.y * E7) * h,
+                (k1.z * E1 + k3.z * E3 + k4.z * E4 + k5.z * E5 + k6.z * E6 + f_new.z * E7) * h};
+    const V3 sc{atol + fmax(fabs(y.x), fabs(y_new.x)) * rtol, atol + fmax(fabs(y.y), fabs(y_new.y)) * rtol,
+                atol + fmax(fabs(y.z), fabs(y_new.z)) * rtol};
+    // error_norm = rms(ev / scale) (rk.py:104-109); the controller only needs err < 1 and err^-0.2, so the kernel
+    // carries err^2 (no sqrt) and divides by reciprocal-multiply (v_rcp_f64 + one Newton step, ~1 ulp)
+    const V3 q{ev.x * rcp_fast(sc.x), ev.y * rcp_fast(sc.y), ev.z * rcp_fast(sc.z)};
+    const double err2 = dot(q, q) * (1.0 / 3.0);
+    const double err = err2;      // compared against squared thresholds below
+    // Controller (rk.py:158-181), branch-free: both outcomes share err^-0.2 and differ in a handful of selects.
+    // 0.9 * err^-0.2 saturates at MAX_FACTOR = 10 for err <= 0.09^5 and at MIN_FACTOR = 0.2 for err >= 4.5^5 (err is
+    // the SQUARED norm here); NaN error norms reject (nan < 1 is False) with fmax(0.2, NaN) = 0.2, as in SciPy.
+    const bool acc = active && err < 1.0;
+    const double r9 = 0.9 * inv_tenth_root(err);
+    // (the clamps also cover the ends of the range: err -> 0 makes r9 huge, inf or -- at exactly 0 -- NaN, and
+    // fmin/fmax return their other operand for a NaN; err -> inf makes it 0 or NaN)
+    double fa = fmin(10.0, r9);
+    fa = L.rejected ? fmin(1.0, fa) : fa;
+    const double fr = fmax(0.2, r9);
+    double h_abs = active ? h_try * (acc ? fa : fr) : L.h_abs;
+    // an accepted attempt advances, records, and does the next step()'s prologue
+    L.t = acc ? t_new : t;
+    L.y = V3{acc ? y_new.x : y.x, acc ? y_new.y : y.y, acc ? y_new.z : y.z};
+    L.f = V3{acc ? f_new.x : L.f.x, acc ? f_new.y : L.f.y, acc ? f_new.z : L.f.z};
+    if (RECORD) { if (acc) llgs_lane_emit<RECORD>(L, out_m, rec, ek); } else L.npts += acc ? 1 : 0;
+    L.rejected = active ? !acc : L.rejected;
+    L.min_step = llgs_min_step_at(L.t);                                                  // unchanged t -> unchanged value
+    const double hc = h_abs > max_step ? max_step : (h_abs < L.min_step ? L.min_step : h_abs);
+    L.h_abs = acc ? hc : h_abs;
+    L.active = active && (L.t != T);
+}
+
+// end of a solve: the final row (the input row when the solve failed), accepted points, attempts
+template <bool RECORD, class NSRC>
+__device__ __forceinline__ SolveOut llgs_lane_finish(LlgsLane& L, V3& out_m, const Recorder& rec, const LlgsEnergyK& ek, const NSRC& ns) {
+    SolveOut o{L.m0, 0, 0, 0, false};
+    if (!RECORD) { llgs_lane_emit<RECORD>(L, out_m, rec, ek); --L.npts; }
+    o.m = out_m;
+    o.n = L.npts - 1;
+    o.work = L.attempts;
+    o.ok = L.ok && !ns.broken;
+    if (!L.ok) o.m = L.m0;
+    return o;
+}
+
+// A7 (+A8 when RECORD): scipy solve_ivp(RK45) as LLGSSolver.solve drives it, one env per lane from start to end.
+template <bool THERMAL, bool RECORD, bool AXIS_Z, class NSRC>
+__device__ __forceinline__ SolveOut llgs_solve(const V3& m0, double J, double T, const LlgsK& k, double beta,
+                                               double betap, double rtol, double atol, double max_step,
+                                               int64_t max_attempts, const RngKey& rk, const Recorder& rec,
+                                               const LlgsEnergyK& ek, NSRC& ns, bool enabled) {
+    const Dp5Tab tb = make_dp5_tab();
+    const V3 zero{0.0, 0.0, 0.0};
+    LlgsLane L;
+    V3 out_m = m0;
+    llgs_lane_begin<THERMAL, RECORD, AXIS_Z>(L, out_m, m0, J, T, k, beta, betap, rtol, atol, max_step, rk, rec, ek, ns, enabled);
     // SharedNormals: the prologue's two RHS calls were chunk 0; every attempt is one further chunk and the loop is
     // wave-uniform (a finished lane idles until the wavefront's last lane is through)
-#ifdef STG_PROFILE_LOOP
-    long long prof_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    long long last_ = __builtin_readcyclecounter();
-    const long long wave_t0_ = last_, wave_r0_ = __builtin_amdgcn_s_memrealtime();
-#endif
-    bool active = enabled && (t != T);       // (a disabled lane only walks the workgroup's chunk loop)
+    WaveProf prof;
+    prof.start();
     bool wave_go = true;
-    if (NSRC::kShared) wave_go = ns.chunk_end(active);
+    if (NSRC::kShared) wave_go = ns.chunk_end(L.active);
     if (wave_go)
     for (;;) {
-      // The loop is wave-uniform and its body has no lane-divergent control flow: a lane that is through (or never
-      // started) walks along with its state frozen by the selects below.  (The lane-divergent form -- break per lane,
-      // exec-masked body -- spent as long on its mask bookkeeping at the top of every iteration as on one RHS.)
+      // The loop is wave-uniform and its body has no lane-divergent control flow (see llgs_lane_attempt).  (The
+      // lane-divergent form -- break per lane, exec-masked body -- spent as long on its mask bookkeeping at the top of every
+      // iteration as on one RHS.)
       // (shared source: the first two fields of the attempt are fetched before anything else, their LDS latency runs
       // under the step-size bookkeeping)
       V3 z2 = zero, z3 = zero;
-      if (THERMAL && NSRC::kShared) { z2 = draw(true); z3 = draw(false); }
-      const bool fail_now = active && (h_abs < min_step || attempts >= max_attempts);     // rk.py:132-133 (+ budget)
-      ok = ok && !fail_now;
-      active = active && !fail_now;
-      if (!NSRC::kShared && __ballot(active) == 0ull) break;
-      STG_TICK(0);
-      {
-        attempts += active ? 1 : 0;
-        double t_new = add_x(t, h_abs);
-        if (t_new - T > 0.0) t_new = T;
-        const double h = sub_x(t_new, t);
-        const double h_try = fabs(h);
-        // rk_step (rk.py:14-70); the one stage time that can pass T is formed without contraction
-        const bool on_end = add_x(t, h) <= T;
-        const V3 k1 = f;
-        // normal-stream phases alternate per call (k2: even, k3: odd, ...); each field is fetched one call ahead
-        if (THERMAL && !NSRC::kShared) { z2 = draw(true); z3 = draw(false); }
-        const V3 k2 = fun(V3{y.x + (k1.x * A21) * h, y.y + (k1.y * A21) * h, y.z + (k1.z * A21) * h}, z2, true);
-        STG_TICK(1);
-        const V3 z4 = draw(true);
-        const V3 k3 = fun(V3{y.x + (k1.x * A31 + k2.x * A32) * h, y.y + (k1.y * A31 + k2.y * A32) * h,
-                             y.z + (k1.z * A31 + k2.z * A32) * h}, z3, true);
-        STG_TICK(2);
-        const V3 z5 = draw(false);
-        const V3 k4 = fun(V3{y.x + (k1.x * A41 + k2.x * A42 + k3.x * A43) * h, y.y + (k1.y * A41 + k2.y * A42 + k3.y * A43) * h,
-                             y.z + (k1.z * A41 + k2.z * A42 + k3.z * A43) * h}, z4, true);
-        STG_TICK(3);
-        const V3 z6 = draw(true);
-        const V3 k5 = fun(V3{y.x + (k1.x * A51 + k2.x * A52 + k3.x * A53 + k4.x * A54) * h,
-                             y.y + (k1.y * A51 + k2.y * A52 + k3.y * A53 + k4.y * A54) * h,
-                             y.z + (k1.z * A51 + k2.z * A52 + k3.z * A53 + k4.z * A54) * h}, z5, true);
-        STG_TICK(4);
-        if (THERMAL) ns.peek();
-        const V3 z7 = draw(false);
-        const V3 k6 = fun(V3{y.x + (k1.x * A61 + k2.x * A62 + k3.x * A63 + k4.x * A64 + k5.x * A65) * h,
-                             y.y + (k1.y * A61 + k2.y * A62 + k3.y * A63 + k4.y * A64 + k5.y * A65) * h,
-                             y.z + (k1.z * A61 + k2.z * A62 + k3.z * A63 + k4.z * A64 + k5.z * A65) * h}, z6, on_end);
-        STG_TICK(5);
-        const V3 y_new{y.x + h * (k1.x * B1 + k3.x * B3 + k4.x * B4 + k5.x * B5 + k6.x * B6),
-                       y.y + h * (k1.y * B1 + k3.y * B3 + k4.y * B4 + k5.y * B5 + k6.y * B6),
-                       y.z + h * (k1.z * B1 + k3.z * B3 + k4.z * B4 + k5.z * B5 + k6.z * B6)};
-        const V3 f_new = fun(y_new, z7, on_end);
-        STG_TICK(6);
-        const V3 ev{(k1.x * E1 + k3.x * E3 + k4.x * E4 + k5.x * E5 + k6.x * E6 + f_new.x * E7) * h,
-                    (k1.y * E1 + k3.y * E3 + k4.y * E4 + k5.y * E5 + k6.y * E6 + f_new.y * E7) * h,
-                    (k1.z * E1 + k3.z * E3 + k4.z * E4 + k5.z * E5 + k6.z * E6 + f_new.z * E7) * h};
-        const V3 sc{atol + fmax(fabs(y.x), fabs(y_new.x)) * rtol, atol + fmax(fabs(y.y), fabs(y_new.y)) * rtol,
-                    atol + fmax(fabs(y.z), fabs(y_new.z)) * rtol};
-        // error_norm = rms(ev / scale) (rk.py:104-109); the controller only needs err < 1 and err^-0.2, so the kernel
-        // carries err^2 (no sqrt) and divides by reciprocal-multiply (v_rcp_f64 + one Newton step, ~1 ulp)
-        const V3 q{ev.x * rcp_fast(sc.x), ev.y * rcp_fast(sc.y), ev.z * rcp_fast(sc.z)};
-        const double err2 = dot(q, q) * (1.0 / 3.0);
-        const double err = err2;      // compared against squared thresholds below
-        // Controller (rk.py:158-181), branch-free: both outcomes share err^-0.2 and differ in a handful of selects.
-        // 0.9 * err^-0.2 saturates at MAX_FACTOR = 10 for err <= 0.09^5 and at MIN_FACTOR = 0.2 for err >= 4.5^5 (err is
-        // the SQUARED norm here); NaN error norms reject (nan < 1 is False) with fmax(0.2, NaN) = 0.2, as in SciPy.
-        const bool acc = active && err < 1.0;
-        const double r9 = 0.9 * inv_tenth_root(err);
-        // (the clamps also cover the ends of the range: err -> 0 makes r9 huge, inf or -- at exactly 0 -- NaN, and
-        // fmin/fmax return their other operand for a NaN; err -> inf makes it 0 or NaN)
-        double fa = fmin(10.0, r9);
-        fa = rejected ? fmin(1.0, fa) : fa;
-        const double fr = fmax(0.2, r9);
-        h_abs = active ? h_try * (acc ? fa : fr) : h_abs;
-        // an accepted attempt advances, records, and does the next step()'s prologue
-        t = acc ? t_new : t;
-        y = V3{acc ? y_new.x : y.x, acc ? y_new.y : y.y, acc ? y_new.z : y.z};
-        f = V3{acc ? f_new.x : f.x, acc ? f_new.y : f.y, acc ? f_new.z : f.z};
-        if (RECORD) { if (acc) emit(); } else npts += acc ? 1 : 0;
-        rejected = active ? !acc : rejected;
-        min_step = min_step_at(t);                                                         // unchanged t -> unchanged value
-        const double hc = h_abs > max_step ? max_step : (h_abs < min_step ? min_step : h_abs);
-        h_abs = acc ? hc : h_abs;
-        active = active && (t != T);
-        STG_TICK(7);
-      }
-      if (NSRC::kShared && !ns.chunk_end(active)) break;
+      if (THERMAL && NSRC::kShared) { z2 = llgs_draw<THERMAL>(ns, k, true); z3 = llgs_draw<THERMAL>(ns, k, false); }
+      llgs_lane_gate(L, max_attempts);
+      if (!NSRC::kShared && __ballot(L.active) == 0ull) break;
+      llgs_lane_attempt<THERMAL, RECORD, AXIS_Z>(L, out_m, k, tb, rtol, atol, max_step, rec, ek, ns, z2, z3);
+      if (NSRC::kShared && !ns.chunk_end(L.active)) break;
     }
-#ifdef STG_PROFILE_LOOP
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        for (int j = 0; j < 10; ++j) g_stg_prof[j] = prof_[j];
-        g_stg_prof[10] = attempts;
-        if constexpr (NSRC::kShared) { g_stg_prof[11] = ns.waited; g_stg_prof[12] = ns.polls; }
-    }
-    {
-        const int wid_ = blockIdx.x * ((int)blockDim.x / 64) + (int)threadIdx.x / 64;
-        long long att_max_ = attempts;
-        for (int o_ = 32; o_ > 0; o_ >>= 1) { const long long v_ = __shfl_xor(att_max_, o_); att_max_ = v_ > att_max_ ? v_ : att_max_; }
-        if ((threadIdx.x & 63) == 0 && wid_ < STG_PROF_WAVES) {
-            long long* r_ = g_stg_wave + 6 * wid_;
-            r_[0] = wave_t0_; r_[1] = __builtin_readcyclecounter(); r_[2] = wave_r0_; r_[3] = __builtin_amdgcn_s_memrealtime();
-            r_[4] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11))      // HW_REG_HW_ID, 32 bits
-                    | ((long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32);    // HW_REG_XCC_ID
-            r_[5] = att_max_;
-        }
-    }
-#endif
-    if (!RECORD) { emit(); --npts; }
-    o.n = npts - 1;
-    o.work = attempts;
-    o.ok = ok && !ns.broken;
-    if (!ok) o.m = m0;
-    return o;
+    prof.stop(L.attempts);
+    return llgs_lane_finish<RECORD>(L, out_m, rec, ek, ns);
 }
 
 // A9: compute_resistance.  ref = normalised reference layer.

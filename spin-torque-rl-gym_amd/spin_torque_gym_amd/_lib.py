@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("STG_HIP_LIBRARY") or os.path.join(_HERE, "libspintorq
 
 STG_MAX_TARGETS = 8
 STG_MAX_CLASSES = 64
-ABI_VERSION = 2          # STG_ABI_VERSION of include/spintorque_hip.h this binding was written against
+ABI_VERSION = 3          # STG_ABI_VERSION of include/spintorque_hip.h this binding was written against
 STG_NPARAM = 30          # double-valued fields of stg_device_params, in declaration order
 SOLVERS = {"rk4": 0, "euler": 1, "rk45": 2}
 DEV_TYPES = {"stt_mram": 0, "sot_mram": 1, "vcma_mram": 2}
@@ -32,6 +32,7 @@ class StgConfig(C.Structure):
         ("targets", (C.c_double * 3) * STG_MAX_TARGETS), ("seed", C.c_uint64), ("max_attempts", C.c_int64),
         ("skip_done", C.c_int32), ("torque_model", C.c_int32), ("wave_spec", C.c_int32), ("lane_sort", C.c_int32),
         ("noise_model", C.c_int32), ("out_layout", C.c_int32), ("noise_corr_time", C.c_double),
+        ("lane_refill", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

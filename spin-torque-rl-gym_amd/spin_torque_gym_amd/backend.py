@@ -41,6 +41,8 @@ class EnvConfig:
     correlation_time: float = 1e-12           # ThermalFluctuations.correlation_time, for noise_model='ou'
     out_layout: str = "soa"                   # 'soa': obs [12,N] + reward/terminated/truncated arrays; 'records': one
                                               # [N,56]-byte record array (what the multi-GPU gather moves, copy-free)
+    lane_refill: Optional[int] = None         # RK45 throughput launches: envs per lane of the lane-refill kernel; None = automatic
+                                              # (>= 262144 envs), False/0 = never, n >= 2 = force (results are bit-identical)
     diagnostics: bool = False                 # also write the step's fp64 reward, per-step energy, status bytes and -- with
                                               # auto-reset -- terminal observations into separate arrays (the C-ABI's optional
                                               # outputs).  Off: those pointers are NULL, a step writes the RL-facing outputs only
@@ -78,6 +80,14 @@ class EnvConfig:
         if self.out_layout not in _lib.OUT_LAYOUTS:
             raise ValueError("out_layout must be 'soa' or 'records'")
         c.out_layout = _lib.OUT_LAYOUTS[self.out_layout]
+        if self.lane_refill is None:
+            c.lane_refill = 0
+        elif not self.lane_refill:
+            c.lane_refill = -1
+        else:
+            if int(self.lane_refill) < 2:
+                raise ValueError("lane_refill must be None (automatic), False / 0 (never) or an integer >= 2 (envs per lane)")
+            c.lane_refill = int(self.lane_refill)
         return c
 
 

@@ -133,7 +133,7 @@ class SpinTorqueVecEnv:
                  max_attempts: int = 200_000, lane_sort: Optional[bool] = None, wave_spec: Optional[bool] = None, torque_model: str = "reference",
                  noise_model: str = "white", correlation_time: float = 1e-12,
                  per_env_params: Optional[Dict[str, Any]] = None, out_layout: str = "records",
-                 diagnostics: bool = False, backend=None):
+                 diagnostics: bool = False, lane_refill: Optional[int] = None, backend=None):
         self.num_envs = int(num_envs)
         factory = DeviceFactory()
         types = [device_type] if isinstance(device_type, str) else list(device_type)
@@ -160,7 +160,7 @@ class SpinTorqueVecEnv:
                              seed=int(self._rng.integers(0, 2**63 - 1)) if seed is None else int(seed),
                              max_attempts=max_attempts, skip_done=skip_done, lane_sort=lane_sort, wave_spec=wave_spec,
                              torque_model=torque_model, noise_model=noise_model, correlation_time=correlation_time,
-                             out_layout=out_layout, diagnostics=bool(diagnostics))
+                             out_layout=out_layout, diagnostics=bool(diagnostics), lane_refill=lane_refill)
         self.autoreset = bool(autoreset)
         self.diagnostics = bool(diagnostics)
         # `backend` is a test seam: a class/callable with HipBackend's constructor signature (tests inject the CPU

@@ -300,6 +300,47 @@ def test_cfg4_per_env_parameters_262144_vs_oracle_slices(stg):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# lane refill of the RK45 step (csrc/stg_kernels.hpp: stg_step_refill_kernel), automatic from 196 608 envs
+# ------------------------------------------------------------------------------------------------------------------
+def test_lane_refill_rk45_thermal_262144_vs_oracle_slices_and_one_env_per_lane(stg):
+    """VERDICT r2 item 2.  The headline workload at 262 144 envs takes the lane-refill kernel by default (4 envs per lane: a
+    lane that has finished its env takes the next one of its wavefront's queue).  Per-env arithmetic is that of the
+    one-env-per-lane kernel, so: (i) oracle slices as everywhere else, (ii) identical bits with lane_refill=False, with 2 and
+    8 envs per lane, and with the identity lane schedule, (iii) identical on-device work counters."""
+    n = 262144
+    m0, tgt, acts = _inputs(n, seed=31, steps=2)
+    kw = dict(device_params=stt_default_params(volume=9.7e-6), include_thermal_fluctuations=True, temperature=300.0, solver="rk45",
+              seed=1234, autoreset=True)
+    hip, c = _run_hip(stg, n, m0, tgt, acts, **kw)                       # automatic: refill, 4 envs per lane
+    assert c["env_steps"] == 2 * n and c["noop_steps"] == 0
+    worst = 0.0
+    for s0 in _slice_starts(n):
+        ora = _run_oracle_slice(stg, s0, m0, tgt, acts, **kw)
+        worst = max(worst, _cmp_slice(hip, ora, slice(s0, s0 + SLICE), TOL_RK45, ("refill 262144", s0)))
+    print("lane refill (262144, rk45 + thermal): worst |dm| vs oracle on slices =", worst)
+    for variant in (dict(lane_refill=False), dict(lane_refill=2), dict(lane_refill=8), dict(lane_sort=False)):
+        other, c2 = _run_hip(stg, n, m0, tgt, acts, **kw, **variant)
+        _assert_same_bits(hip, other, ("refill variant", variant))
+        assert c2 == c, (variant, c2, c)
+
+
+@pytest.mark.parametrize("thermal", [False, True])
+def test_lane_refill_ragged_sizes_and_class_tables(stg, thermal):
+    """Forced refill on sizes that are no multiple of anything (last block, last queue round and last tile incomplete; fewer
+    blocks than rounds), with a class table in LDS, T = 0 K and thermal: bit-identical to one env per lane."""
+    q = stt_default_params(volume=9.7e-6, damping=0.02, polarization=0.5)
+    for n, r in ((200001, 3), (4096 * 5 + 70, 2), (130, 4), (64, 2), (9000, 7)):
+        m0, tgt, acts = _inputs(n, seed=n, steps=2, thi=4e-10)
+        cls = (np.arange(n) % 2).astype(np.uint8)
+        kw = dict(device_type=["stt_mram", "stt_mram"], device_params=[stt_default_params(volume=9.7e-6), q],
+                  include_thermal_fluctuations=thermal, solver="rk45", seed=5, autoreset=True, max_steps=2, wave_spec=False)
+        base, c0 = _run_hip(stg, n, m0, tgt, acts, cls=cls, lane_refill=False, **kw)
+        ref, c1 = _run_hip(stg, n, m0, tgt, acts, cls=cls, lane_refill=r, **kw)
+        _assert_same_bits(base, ref, ("refill ragged", n, r, thermal))
+        assert c0 == c1
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # cfg 2: 4096 envs, T = 0 K, RK45 -- every env
 # ------------------------------------------------------------------------------------------------------------------
 def test_cfg2_rk45_4096_every_env_vs_oracle(stg):

@@ -33,7 +33,7 @@ def stg():
 
 def _backend(stg, n, table, cls=None, **cfg):
     from spin_torque_gym_amd.backend import EnvConfig, HipBackend
-    b = HipBackend(n, EnvConfig(**cfg))
+    b = HipBackend(n, EnvConfig(**{"diagnostics": True, **cfg}))
     b.set_params(table, cls)
     return b
 
@@ -334,7 +334,7 @@ def test_full_size_properties_65536(stg):
     act[0] = torch.tensor(rng.uniform(-2e6, 2e6, n), dtype=torch.float32)
     act[1] = torch.tensor(rng.uniform(1e-10, 3e-10, n), dtype=torch.float32)
     table = [_flat(stg, stt_default_params(volume=8.75e-11))]
-    cfg = EnvConfig(solver="rk4", include_thermal_fluctuations=True, seed=99)
+    cfg = EnvConfig(solver="rk4", include_thermal_fluctuations=True, seed=99, diagnostics=True)
 
     def run(n_sub, off):
         b = HipBackend(n_sub, cfg, env_id0=off)
@@ -530,7 +530,7 @@ def test_step_is_hip_graph_capturable(stg, layout):
     from spin_torque_gym_amd.backend import EnvConfig, HipBackend
     n = 8192
     table = [_flat(stg, stt_default_params(volume=8.75e-11))]
-    cfg = EnvConfig(solver="rk4", include_thermal_fluctuations=True, seed=3, lane_sort=True, out_layout=layout)
+    cfg = EnvConfig(solver="rk4", include_thermal_fluctuations=True, seed=3, lane_sort=True, out_layout=layout, diagnostics=True)
     rng = np.random.default_rng(0)
     acts = torch.tensor(_uniform_actions(2e6, 1e-10, 3e-10)(rng, n, 0).T.copy(), device="cuda")
     res = []
@@ -563,7 +563,7 @@ def test_config5_shard_size_and_ragged_batches(stg):
     the wavefront, N = 1).  Size-independent properties: |m| = 1, counters add up, sub-batches equal the full batch."""
     from spin_torque_gym_amd.backend import EnvConfig, HipBackend
     table = [_flat(stg, stt_default_params(volume=8.75e-11))]
-    cfg = EnvConfig(solver="rk4", include_thermal_fluctuations=True, seed=17)
+    cfg = EnvConfig(solver="rk4", include_thermal_fluctuations=True, seed=17, diagnostics=True)
     n = 1048576
     g = torch.Generator().manual_seed(1)
     v = torch.randn((3, n), generator=g, dtype=torch.float64)

@@ -19,9 +19,6 @@ timeout -k 10 400 python3 bench.py > $out/bench.json 2> $out/bench.err || echo "
     STG_HIP_LIBRARY=$PWD/build/lib_prof.so timeout -k 10 120 python3 tools/probe_wave_records.py 65536 1 3 8
     echo "== tools/probe_wave_records.py 65536 0 2 8"
     STG_HIP_LIBRARY=$PWD/build/lib_prof.so timeout -k 10 120 python3 tools/probe_wave_records.py 65536 0 2 8
-    echo "== tools/probe_loop_profile.py 65536 1 1 / 4096 0 0"
-    STG_HIP_LIBRARY=$PWD/build/lib_prof.so timeout -k 10 120 python3 tools/probe_loop_profile.py 65536 1 1
-    STG_HIP_LIBRARY=$PWD/build/lib_prof.so timeout -k 10 120 python3 tools/probe_loop_profile.py 4096 0 0
   fi
 } > $out/probes.txt 2>&1
 timeout -k 10 200 python3 -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.txt 2>&1 || echo "smoke failed"
