@@ -575,11 +575,11 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
     // experiment knob STG_REFILL=<envs per lane>[,<attempts between refill points>] overrides the configuration
     a.refill = 0; a.refill_check = STG_REFILL_CHECK_DEFAULT;
     if (ctx->cfg.solver == STG_SOLVER_RK45 && K == 1 && !ctx->per_env && !ctx->cfg.skip_done) {
-        int r = ctx->cfg.lane_refill > 0 ? ctx->cfg.lane_refill
-                                         : (ctx->cfg.lane_refill == 0 ? refill_auto(ctx->N) : 0);
+        int r = ctx->cfg.lane_refill > 0 ? ctx->cfg.lane_refill : (ctx->cfg.lane_refill == 0 ? refill_auto(ctx->N) : 0);
         int chk = STG_REFILL_CHECK_DEFAULT;
         if (ctx->refill >= 0) { r = ctx->refill; chk = ctx->refill_check; }
-        if (r >= 2 && !(ctx->cfg.thermal && pc)) {
+        // (not combined with the wave-specialised launch: a forced wave_spec = 1 keeps the one-env-per-lane kernel)
+        if (r >= 2 && !(ctx->cfg.thermal && ctx->cfg.wave_spec > 0)) {
             a.refill = r; a.refill_check = chk > 0 ? chk : STG_REFILL_CHECK_DEFAULT;
             stg_dispatch_step_rk45_refill(a, ctx->cfg.thermal != 0, multi, ctx->axis_z_llgs, act_f64, st);
             HIP_TRY(hipGetLastError());
