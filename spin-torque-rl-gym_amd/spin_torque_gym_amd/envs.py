@@ -553,13 +553,26 @@ def _parse_action_host(a: np.ndarray, max_current: float, max_duration: float):
     return J, T
 
 
+# What the reference has registered once `spin_torque_gym` and `spin_torque_gym.envs` are imported: both modules register the
+# same ids, the second registration (envs/__init__.py:14-26) replaces the first (__init__.py:14-24).
+REGISTRATIONS = {
+    "SpinTorque-v0": dict(entry_point="spin_torque_gym_amd.envs:SpinTorqueEnv", max_episode_steps=100,
+                          kwargs={"device_type": "stt_mram"}),
+    "SpinTorqueArray-v0": dict(entry_point="spin_torque_gym_amd.array_env:SpinTorqueArrayEnv", max_episode_steps=200,
+                               kwargs={"array_size": (4, 4), "device_type": "stt_mram"}),
+}
+
+
 def register_envs():
-    """Registers 'SpinTorque-v0' with Gymnasium when it is installed (reference: spin_torque_gym/__init__.py:14-18,
-    envs/__init__.py:14-19; the second registration, max_episode_steps=100, is the one that sticks)."""
+    """Registers 'SpinTorque-v0' and 'SpinTorqueArray-v0' with Gymnasium when it is installed, with the reference's final
+    `max_episode_steps` and kwargs (reference: spin_torque_gym/__init__.py:14-24, envs/__init__.py:14-26), so that
+    ``gym.make('SpinTorque-v0', **kwargs)`` builds the GPU-backed classes.  Called on ``import spin_torque_gym_amd``.
+    ('SkyrmionRacetrack-v0' is a different physics and out of scope)"""
     if _gym is None:
         return False
     from gymnasium.envs.registration import register, registry
-    if "SpinTorque-v0" not in registry:
-        register(id="SpinTorque-v0", entry_point="spin_torque_gym_amd.envs:SpinTorqueEnv", max_episode_steps=100,
-                 kwargs={"device_type": "stt_mram"})
+    for env_id, spec in REGISTRATIONS.items():
+        if env_id not in registry:
+            register(id=env_id, entry_point=spec["entry_point"], max_episode_steps=spec["max_episode_steps"],
+                     kwargs=dict(spec["kwargs"]))
     return True

@@ -74,6 +74,20 @@ def register(id, entry_point=None, max_episode_steps=None, kwargs=None, **_):
     _registry[id] = dict(entry_point=entry_point, max_episode_steps=max_episode_steps, kwargs=kwargs or {})
 
 
+def make(id, **kwargs):
+    """gymnasium.make without the wrappers: resolves the registered entry point ("module:attr"), merges the registered kwargs
+    with the caller's and instantiates.  The spec is left on the env as `.spec` (a dict)."""
+    import importlib
+    spec = _registry[id]
+    ep = spec["entry_point"]
+    if isinstance(ep, str):
+        mod, attr = ep.split(":")
+        ep = getattr(importlib.import_module(mod), attr)
+    env = ep(**{**spec["kwargs"], **kwargs})
+    env.spec = dict(spec, id=id)
+    return env
+
+
 def install():
     """Register the stub under the name ``gymnasium`` in sys.modules."""
     if "gymnasium" in sys.modules:
@@ -91,7 +105,7 @@ def install():
     seeding = types.ModuleType("gymnasium.utils.seeding")
     seeding.np_random = np_random
     utils.seeding = seeding
-    g.spaces, g.envs, g.utils, g.register = spaces, envs, utils, register
+    g.spaces, g.envs, g.utils, g.register, g.make = spaces, envs, utils, register, make
     for name, mod in [("gymnasium", g), ("gymnasium.spaces", spaces), ("gymnasium.envs", envs),
                       ("gymnasium.envs.registration", reg), ("gymnasium.utils", utils),
                       ("gymnasium.utils.seeding", seeding)]:

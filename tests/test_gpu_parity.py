@@ -156,6 +156,46 @@ def test_env_episodes_vs_golden_g6(stg, golden):
         env.close()
 
 
+def test_cfg1_single_env_rk45_step_through_the_facade(stg, golden):
+    """BASELINE cfg1 as worded -- "single STT-MRAM macrospin, SpinTorque-v0 default params, RK45, thermal off" -- through
+    `SpinTorqueEnv(solver='rk45').step()`: reset with the initial state of every G4 relaxation (the
+    unmodified reference's LLGSSolver.solve: default STT parameters, J = 0, T = 0.1 / 1 ns), ONE step((0, T)).
+    (i) float64 action (T is the golden's exact double): the env's magnetisation equals the reference trajectory's last row to
+    1e-8; (ii) float32 action (what the reference env casts to; T is then 2.8e-17 s off for 1 ns): observation / reward / flags /
+    info equal the same facade on the oracle backend, whose C entry takes float32 actions."""
+    from helpers import OracleBackend
+    g = golden("G4_llgs_rk45_relax")
+    worst = 0.0
+    z = np.array([0.0, 0.0, 1.0])
+
+    def one_step(backend, m0, action):
+        env = stg.SpinTorqueEnv(include_thermal_fluctuations=False, solver="rk45", backend=backend)
+        assert env.get_solver_info()["method"] == "rk45"
+        obs0, _ = env.reset(seed=0, options={"initial_state": m0, "target_state": z})
+        obs, r, te, tr, info = env.step(action)
+        assert "error" not in info, info
+        out = (obs0, obs, r, te, tr, info["simulation_success"], info["energy_consumed"], info["pulse_duration"],
+               env.current_magnetization.copy(), env.step_count)
+        env.close()
+        return out
+    for k, case in enumerate(g["cases"]):
+        m0, T, J = case[:3], float(case[3]), float(case[4])
+        assert J == 0.0
+        h = one_step(None, m0, np.array([J, T], dtype=np.float64))
+        assert h[7] == T and h[5] is True and h[9] == 1 and h[6] == 0.0
+        d = np.abs(h[8] - g[f"m_{k}"][-1]).max()
+        worst = max(worst, d)
+        assert d <= TOL_RK45, (k, d)
+        assert np.allclose(h[1][:3], g[f"m_{k}"][-1].astype(np.float32), rtol=3e-7, atol=1e-9)      # obs[:3] = m as float32
+        h32, o32 = (one_step(b, m0, np.array([J, T], dtype=np.float32)) for b in (None, OracleBackend))
+        assert np.array_equal(h32[0], o32[0]) and np.allclose(h32[1], o32[1], rtol=3e-7, atol=1e-9), k
+        assert abs(h32[2] - o32[2]) <= 1e-8 and h32[3:8] == o32[3:8] and h32[9] == o32[9] == 1, (k, h32[2:8], o32[2:8])
+        assert np.abs(h32[8] - o32[8]).max() <= TOL_RK45
+        # the float32 duration's own effect on the end point: |dm/dt| <= gamma H_k ~ 5.3e11 /s times the rounding of T
+        assert np.abs(h32[8] - g[f"m_{k}"][-1]).max() <= 1e-8 + 1.5 * 5.3e11 * abs(float(np.float32(T)) - T)
+    print("cfg1: SpinTorqueEnv(solver='rk45').step vs the reference's G4 final rows: worst |dm| =", worst)
+
+
 def test_reset_seed_parity_g9(stg, golden):
     """reset(seed=s) reproduces the reference's PCG64 draws (tests/integration/test_environment.py:77-93)."""
     g = golden("G9_reset_seeds")
