@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -69,9 +70,15 @@ __device__ __forceinline__ V3 device_field(const V3& m_in, const ArrDev& d) {
 __device__ __forceinline__ int64_t obs_row_pattern(int obs_mode, int n, int d, int k) { return obs_mode == 0 ? d * 6 + k : d * 3 + k; }
 __device__ __forceinline__ int64_t obs_row_target(int obs_mode, int n, int d, int k) { return obs_mode == 0 ? d * 6 + 3 + k : 3 * n + d * 3 + k; }
 
+// NDEV > 0: the number of cells is a compile-time constant and the coupling sum unrolls (4 x 4, the registered
+// SpinTorqueArray-v0: 'global' mode 0.178 -> 0.167 ms per launch at 262 144 arrays, 'row' / 'column' unchanged).
+// (Round 3, measured and rejected: a software-pipelined sweep that forms the coupling sum of the NEXT addressed cell -- all
+// terms but the current cell's -- before the current cell's ten dependent Euler sub-steps and adds that one term afterwards:
+// 0.169-0.172 ms against 0.167-0.168 ms for the plain unrolled form; the launch is not bound by that dependency chain.)
+template <int NDEV>
 __global__ void __launch_bounds__(64) stg_array_step_kernel(const ArrArgs a) {
     extern __shared__ double lds[];           // pattern [n*3][64] then coupling [n*n]
-    const int n = a.rows * a.cols;
+    const int n = NDEV > 0 ? NDEV : a.rows * a.cols;
     double* lp = lds;
     double* lc = lds + (size_t)n * 3 * 64;
     const int lane = threadIdx.x;
@@ -121,13 +128,17 @@ __global__ void __launch_bounds__(64) stg_array_step_kernel(const ArrArgs a) {
     const bool drive = fabs(J) > 1e-12;                                                // array_env.py:506
     double e_total = 0.0;
     if (drive) {
+        // The addressed cells update sequentially and each sees its predecessors' new states through the coupling sum
+        // (the reference updates current_pattern in place, array_env.py:447-476).
+#pragma unroll 1
         for (int q = 0; q < count; ++q) {
             const int d = first + q * stride;
             const V3 m0{lp[(d * 3) * 64 + lane], lp[(d * 3 + 1) * 64 + lane], lp[(d * 3 + 2) * 64 + lane]};
             V3 h = device_field(m0, a.dev);
             if (a.include_coupling) {                                                  // array_env.py:485-492
                 V3 hc{0.0, 0.0, 0.0};
-                for (int j = 0; j < n; ++j) {
+#pragma unroll
+                for (int j = 0; j < (NDEV > 0 ? NDEV : n); ++j) {
                     const double c = (j == d) ? 0.0 : lc[d * n + j];
                     hc = V3{hc.x + c * lp[(j * 3) * 64 + lane], hc.y + c * lp[(j * 3 + 1) * 64 + lane],
                             hc.z + c * lp[(j * 3 + 2) * 64 + lane]};
@@ -410,6 +421,7 @@ struct stg_array_ctx {
     int32_t* step;
     uint32_t* resets;
     bool have_state = false, have_target = false;
+    int variant = 1;          // experiment knob STG_ARRAY_VARIANT: 0 generic kernel for every size, 1 (default) unrolled 4 x 4
 };
 
 extern "C" {
@@ -433,6 +445,7 @@ int stg_array_create(stg_array_ctx** out, int device_id, int64_t n_arrays, int64
     stg_array_ctx* c = new (std::nothrow) stg_array_ctx();
     if (!c) return afail(STG_E_NOMEM, "out of host memory");
     c->device = device_id; c->N = n_arrays; c->env_id0 = env_id0; c->cfg = *cfg;
+    if (const char* e = std::getenv("STG_ARRAY_VARIANT")) c->variant = std::atoi(e);
     const double mu0 = 4 * M_PI * 1e-7;
     ArrDev& d = c->dev;
     d.hk = 2 * p->ku / (mu0 * p->ms); d.ms = p->ms;                       // stt_mram.py:71, sot_mram.py:93
@@ -511,9 +524,15 @@ int stg_array_step(stg_array_ctx* ctx, const float* actions, float* obs, float* 
         return STG_OK;
     }
     const size_t lds = sizeof(double) * ((size_t)n * 3 * 64 + (c.include_coupling ? (size_t)n * n : 0));
-    if (lds > 48 * 1024)
-        AHIP_TRY(hipFuncSetAttribute((const void*)stg_array_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(stg_array_step_kernel, dim3((unsigned)((ctx->N + 63) / 64)), dim3(64), lds, (hipStream_t)stream, a);
+    const dim3 grid((unsigned)((ctx->N + 63) / 64));
+    if (n == 16 && ctx->variant != 0) {
+        // 4 x 4 arrays (the registered SpinTorqueArray-v0): the coupling sum unrolled
+        hipLaunchKernelGGL((stg_array_step_kernel<16>), grid, dim3(64), lds, (hipStream_t)stream, a);
+    } else {
+        if (lds > 48 * 1024)
+            AHIP_TRY(hipFuncSetAttribute((const void*)stg_array_step_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((stg_array_step_kernel<0>), grid, dim3(64), lds, (hipStream_t)stream, a);
+    }
     AHIP_TRY(hipGetLastError());
     return STG_OK;
 }
