@@ -14,9 +14,21 @@ Headline workload (config.workload): BASELINE.json configs[2] / the north-star t
 per GPU, thermal field on at 300 K (in-kernel Philox), LLGSSolver semantics (SciPy RK45, rtol 1e-6, atol 1e-9,
 max_step 1 ps), random pulses J ~ U[-2e6, 2e6] A/m^2, duration ~ U[0.1, 1] ns (float32), `volume` rescaled to 9.7e-6 so
 that the Slonczewski term is well conditioned for RK45 (SURVEY.md headline 3: at the default volume any J != 0 makes
-the reference's solver diverge), device-side auto-reset of finished episodes.  `also` carries the other
-configurations (cfg2: 4096 envs T = 0 K; the env's own RK4 solver; cfg4: 262 144 mixed STT/SOT/VCMA envs; cfg2a; the
-array env).  Every configuration timed here is compared with the oracle at the same size in tests/test_gpu_fullsize.py.
+the reference's solver diverge), device-side auto-reset of finished episodes, the env's default outputs (diagnostics
+off: obs / reward / terminated / truncated records only).  `also` carries the other configurations (cfg2: 4096 envs
+T = 0 K; the env's own RK4 solver; one cfg5 shard; cfg4: 262 144 mixed STT/SOT/VCMA envs with a class table, with the
+device-physics torque terms, and with one parameter record per env; cfg2a; the array env).  Every configuration timed
+here is compared with the oracle at the same size in tests/test_gpu_fullsize.py.
+
+What is timed.  `value` / `ms_per_step`: host wall time of ONE block of exactly --steps calls of the C-ABI step
+(HipBackend.step -> stg_step_many) between synchronizes (+ barriers for N > 1), max over ranks.  `api_ms_per_step`: the
+same steps through the public SpinTorqueVecEnv.step() with Gym-convention [N, 2] actions (headline and cfg2).
+Timing hygiene (profiles/r03_stall_root_cause.txt): the GPU boxes show 256 CPUs but the container's CFS quota is 16; torch's
+default pool of 128 host threads made the container get THROTTLED for up to 100 ms right after a row's set-up -- the
+"sporadic ~80 ms stall" of rounds 1-2.  The pool is capped (cap_host_threads), the collector is off inside a block, events
+exist before the block, and a block is timed again (at most twice) ONLY if cgroup cpu.stat reports a throttling event during
+it -- never on the measured times.  Every block's wall time is printed: `block_walls_ms`, `block_throttled`, `blocks_timed`
+are the LAST keys of the line.
 
 Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 
@@ -31,6 +43,10 @@ The counters are collected LIVE: at N = 1 this script first runs itself three ti
 BEFORE this process touches the GPU, and maps the dispatches to the rows through marker launches.  If rocprofv3 is not
 usable, the committed table profiles/r03_pmc_rows.json is used when it was measured on this very library build (sha256
 of the .so), and `frac`/`traffic` are null otherwise: no stale number is ever printed.
+
+N > 1: check_ranks() asserts that the process group spans --gpus ranks on as many distinct GPUs (RCCL); besides the
+pipelined loop the line carries `no_gather` (no exchange at all) and `gather_only` with the exchange by itself for all
+three forms (all_gather, in-place all_gather, one-shot p2p) in one run.
 """
 import argparse
 import csv
@@ -69,7 +85,7 @@ PMC_PASSES = {
     "write": "WRITE_SIZE",
 }
 PMC_TABLE = os.path.join(ROOT, "profiles", "r03_pmc_rows.json")
-MAIN_KERNELS = ("stg_step_kernel", "stg_array_step_kernel", "stg_array_step_individual_kernel")
+MAIN_KERNELS = ("stg_step_kernel", "stg_step_refill_kernel", "stg_array_step_kernel", "stg_array_step_individual_kernel")
 MARKER_KERNEL = "stg_normals_kernel"
 
 
