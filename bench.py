@@ -883,8 +883,12 @@ def main():
         dist.all_reduce(gm, op=dist.ReduceOp.MAX)
         out["gather_only"] = {"ms": round(float(gm.item()), 4), "bytes_per_rank": 56 * n_local, "algo": args.gather_algo,
                               "note": "the exchange by itself, back to back with nothing to hide under (max over ranks); in the "
-                                      "timed loop it runs on its own stream under the next step's kernel",
-                              "all_algos_ms": gather_only_all_algos(n_local, args.solver, args.thermal, args.steps, rank, world, local_rank)}
+                                      "timed loop it runs on its own stream under the next step's kernel"}
+        if rank == 0:
+            # the in-place all-gather and the point-to-point exchange below have never run over RCCL with N > 1 (one-GPU build
+            # boxes): a safety copy of the measured line goes to stderr first, in case one of them does not come back
+            print("bench.py (before the exchange sweep): " + json.dumps(dict(out, **block_report_of(meas))), file=sys.stderr, flush=True)
+        out["gather_only"]["all_algos_ms"] = gather_only_all_algos(n_local, args.solver, args.thermal, args.steps, rank, world, local_rank)
     if rank == 0 and world == 1 and args.also:
         also = []
         for key, spec in specs[1:]:

@@ -1208,6 +1208,9 @@ def test_c_abi_error_behaviour(stg):
     assert lib.stg_create(C.byref(ctx), 0, 64, 0, C.byref(bad)) < 0
     bad = EnvConfig(solver="rk45").to_abi(); bad.noise_model = 1
     assert lib.stg_create(C.byref(ctx), 0, 64, 0, C.byref(bad)) < 0 and b"fixed-step" in lib.stg_last_error()
+    for field, val in (("lane_refill", 1), ("lane_refill", -2), ("lane_refill", 5000), ("reserved0", 7)):     # ABI v3
+        bad = EnvConfig(solver="rk45").to_abi(); setattr(bad, field, val)
+        assert lib.stg_create(C.byref(ctx), 0, 64, 0, C.byref(bad)) == _lib.STG_E_INVALID and field.encode() in lib.stg_last_error()
     assert lib.stg_create(C.byref(ctx), 0, 64, 0, C.byref(cfg)) == 0
     n = 64
     dev = torch.device("cuda", 0)

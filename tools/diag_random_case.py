@@ -32,7 +32,7 @@ for case in range(cases):
     tgt = np.where(r0.integers(0, 2, (n, 1)) == 0, 1.0, -1.0) * np.array([[0.0, 0.0, 1.0]])
     res = {}
     for name, kw in (("hip", {}), ("hip_ws_off", dict(wave_spec=False)), ("oracle", dict(backend=OracleBackend))):
-        env = stg.SpinTorqueVecEnv(n, seed=seed, device_params=par, include_thermal_fluctuations=thermal, solver=solver,
+        env = stg.SpinTorqueVecEnv(n, diagnostics=True, seed=seed, device_params=par, include_thermal_fluctuations=thermal, solver=solver,
                                    max_duration=5e-9, **kw)
         env.reset(options={"initial_state": m0, "target_state": tgt})
         arng = np.random.default_rng(seed + 1)

@@ -26,7 +26,7 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 36):
               skip_done=(mode == "skip_done"), autoreset=(mode == "autoreset"), noise_model="ou" if ou else "white")
     outs = []
     for ws in (False, True):
-        env = stg.SpinTorqueVecEnv(n, wave_spec=ws, **kw)
+        env = stg.SpinTorqueVecEnv(n, wave_spec=ws, diagnostics=True, **kw)
         env.reset(seed=case)
         o1, r1, te1, tr1, i1 = env.step(torch.from_numpy(acts[0]))
         om, rm, tem, trm, im = env.step_many(torch.from_numpy(acts))
