@@ -726,13 +726,46 @@ static size_t step_dyn_lds(const StepArgs& a) {
     return MULTI ? (size_t)(a.ep.soa ? 64 : a.ncls) * C_COUNT * sizeof(double) : 0;
 }
 
+// Workgroups of this kernel a CU holds at once (registers, LDS), asked of the runtime once per (kernel, LDS size) and thread.
+template <class KernelT>
+static int resident_workgroups_per_cu(KernelT kernel, int block, size_t lds) {
+    struct Key { const void* f; size_t lds; int v; };
+    static thread_local Key cache[8] = {};
+    static thread_local int used = 0;
+    for (int j = 0; j < used; ++j) if (cache[j].f == (const void*)kernel && cache[j].lds == lds) return cache[j].v;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, lds) != hipSuccess || nb < 1) nb = 2;
+    if (used < 8) cache[used++] = Key{(const void*)kernel, lds, nb};
+    return nb;
+}
+
+// The boustrophedon workgroup order (stg_slot_block) pays exactly when every workgroup of an XCD group is resident from the
+// start -- then the dispatcher's assignment to the 32 CUs is static and the plain longest-first order stacks the longest
+// workgroup of EVERY round on the first CUs.  Whether that is so depends on the kernel's occupancy: the T = 0 K fixed-step
+// kernels hold four workgroups of four wavefronts per CU (262 144 envs = four rounds, all resident: cfg4 0.532 -> 0.500 ms, RK4
+// at T = 0 K 0.54 -> 0.49 ms with the snake), the device-physics and thermal ones three or two (the later rounds go to whichever
+// CU frees up first, where longest-first is better: 0.73 -> 0.79 ms with the snake).  So the host asks the runtime.
+template <class KernelT>
+static StepArgs with_snake_rule(const StepArgs& a, KernelT kernel, int wgw, size_t lds, unsigned nwg) {
+    StepArgs b = a;
+    if (!a.perm || (a.walk & (int32_t)(STG_WALK_SNAKE_ON | STG_WALK_SNAKE_OFF))) return b;          // identity schedule / forced by STG_SNAKE
+    const unsigned tile_wgs = (unsigned)(TILE_WAVES / wgw), n_q = (nwg / (8u * tile_wgs)) * tile_wgs;   // workgroups per XCD group
+    const int nb = resident_workgroups_per_cu(kernel, wgw * 64, lds);
+    b.walk |= (int32_t)((n_q > 32u && n_q <= 32u * (unsigned)nb) ? STG_WALK_SNAKE_ON : STG_WALK_SNAKE_OFF);
+    return b;
+}
+
 template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, bool DEVPHYS, int WGW>
 static void launch_step_w(const StepArgs& a, int act_f64, bool pc, hipStream_t st) {
     const dim3 grid((unsigned)((a.N + WGW * 64 - 1) / (WGW * 64)));
-    if (act_f64)
-        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, double, false, WGW>), grid, dim3(WGW * 64), step_dyn_lds<MULTI>(a), st, a);
-    else
-        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, float, false, WGW>), grid, dim3(WGW * 64), step_dyn_lds<MULTI>(a), st, a);
+    const size_t lds = step_dyn_lds<MULTI>(a);
+    if (act_f64) {
+        auto k = stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, double, false, WGW>;
+        hipLaunchKernelGGL(k, grid, dim3(WGW * 64), lds, st, with_snake_rule(a, k, WGW, lds, grid.x));
+    } else {
+        auto k = stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, float, false, WGW>;
+        hipLaunchKernelGGL(k, grid, dim3(WGW * 64), lds, st, with_snake_rule(a, k, WGW, lds, grid.x));
+    }
 }
 
 template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, bool DEVPHYS>
