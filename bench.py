@@ -783,12 +783,14 @@ def child_argv(args):
 
 def check_ranks(args, rank, local_rank, world):
     """N > 1: every rank reports (rank, local device index, PCI domain/bus/device of its GPU) through the process group
-    itself; asserts that the collective library really spans `--gpus` ranks and, with RCCL, that no two ranks share a GPU."""
+    itself; asserts that the collective library really spans `--gpus` ranks and, with RCCL, that no two ranks share a GPU
+    (by PCI address where torch exposes it, else by the local device index)."""
     import torch.distributed as dist
     dev = torch.device("cuda", local_rank)
     pr = torch.cuda.get_device_properties(local_rank)
-    mine = torch.tensor([rank, local_rank, getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)],
-                        dtype=torch.int64, device=dev)
+    have_pci = all(hasattr(pr, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    ident = (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id) if have_pci else (-1, -1, local_rank)
+    mine = torch.tensor([rank, local_rank, *ident], dtype=torch.int64, device=dev)
     allr = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(allr, mine)
     rows = [tuple(int(x) for x in t.tolist()) for t in allr]
@@ -798,7 +800,7 @@ def check_ranks(args, rank, local_rank, world):
     if args.backend == "nccl" and len(gpus) != world:
         raise SystemExit(f"{world} RCCL ranks on {len(gpus)} distinct GPUs: {rows}")
     return {"ranks_seen": len(rows), "distinct_gpus": len(gpus), "backend": dist.get_backend(),
-            "pci": ["%04x:%02x:%02x" % r[2:] for r in sorted(rows)]}
+            "gpus": [("%04x:%02x:%02x" % r[2:]) if r[2] >= 0 else f"cuda:{r[4]}" for r in sorted(rows)]}
 
 
 def main():
