@@ -794,13 +794,15 @@ static void dispatch_step2(const StepArgs& a, bool thermal, bool multi, int act_
 // devphys the opt-in device-physics torque model (fixed-step solvers only)
 template <int SOLVER>
 static void dispatch_step(const StepArgs& a, bool thermal, bool multi, bool axis_z, bool devphys, int act_f64, bool pc, hipStream_t st) {
-    if (SOLVER != STG_SOLVER_RK45 && devphys) {
-        if (axis_z) dispatch_step2<SOLVER, true, true>(a, thermal, multi, act_f64, pc, st);
-        else dispatch_step2<SOLVER, false, true>(a, thermal, multi, act_f64, pc, st);
-    } else {
-        if (axis_z) dispatch_step2<SOLVER, true, false>(a, thermal, multi, act_f64, pc, st);
-        else dispatch_step2<SOLVER, false, false>(a, thermal, multi, act_f64, pc, st);
+    if constexpr (SOLVER != STG_SOLVER_RK45) {          // (the device-physics torque model exists for the fixed-step solvers only)
+        if (devphys) {
+            if (axis_z) dispatch_step2<SOLVER, true, true>(a, thermal, multi, act_f64, pc, st);
+            else dispatch_step2<SOLVER, false, true>(a, thermal, multi, act_f64, pc, st);
+            return;
+        }
     }
+    if (axis_z) dispatch_step2<SOLVER, true, false>(a, thermal, multi, act_f64, pc, st);
+    else dispatch_step2<SOLVER, false, false>(a, thermal, multi, act_f64, pc, st);
 }
 
 // lane-refill launch of the RK45 step (a.refill = envs per lane >= 2): ceil(ceil(N / 64) / refill) wavefronts
