@@ -122,12 +122,13 @@ typedef struct {
                                        [N_global, 12] strided view of it (Gym's own orientation), no transposition or
                                        concatenation copy anywhere. */
     double noise_corr_time;         /* correlation_time of ThermalFluctuations (default 1e-12 s); used when noise_model = 1 */
-    int32_t lane_refill;            /* STG_SOLVER_RK45, single-step launches: every wavefront owns a queue of lane_refill x 64 envs of
-                                       the sorted schedule and a lane that has finished its env takes the next one while its
-                                       neighbours keep integrating (ABI v3).  0 = automatic (launches of >= 196608 envs:
-                                       N / 65536 envs per lane, at most 8), -1 = never, >= 2 = that many envs per lane.  Per-env arithmetic is
-                                       untouched: results are bit-identical to the one-env-per-lane launch.  Not used with
-                                       skip_done, per-env parameter records, fused steps (K > 1) or the wave-specialised launch. */
+    int32_t lane_refill;            /* STG_SOLVER_RK45, single-step launches: every wavefront owns a queue of 64-env blocks of the sorted
+                                       schedule and a lane that has finished its env takes the next one while its neighbours keep
+                                       integrating (ABI v3).  0 = automatic (launches of >= 196608 envs: 1024 queues -- one refill
+                                       wavefront per SIMD -- up to 8 envs per lane, 2048 queues beyond), -1 = never, >= 2 = that many
+                                       envs per lane.  Per-env arithmetic is untouched: results are bit-identical to the
+                                       one-env-per-lane launch.  Not used with skip_done, per-env parameter records, fused steps
+                                       (K > 1) or a forced wave_spec = 1. */
     int32_t reserved0;              /* must be 0 */
 } stg_config;
 

@@ -257,15 +257,20 @@ static int fail(int code, const std::string& msg) {
             return fail(STG_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
     } while (0)
 
-// automatic lane refill of the RK45 step (measured on 262144 ... 1048576 envs): envs per lane = N / 65536
-// (one refill wavefront per SIMD), at most 8 (then two and more per SIMD); below 3 envs per lane the refill launch has nothing
-// over the one-env-per-lane launch with its two wavefronts per SIMD.  Attempts between refill points: 64.
+// automatic lane refill of the RK45 step (measured on 196 608 ... 1 048 576 envs): from 196 608 envs, with
+// 1024 queues (one refill wavefront per SIMD; the 64-env blocks are dealt over them, so any batch size loads them evenly to within
+// one short block) while that leaves at most 8 envs per lane, else 2048 queues.  Below 3 envs per lane the refill launch has
+// nothing over the one-env-per-lane launch with its two wavefronts per SIMD.  Attempts between refill points: 64.
 constexpr int64_t STG_REFILL_AUTO_ENVS = 196608;
 constexpr int32_t STG_REFILL_CHECK_DEFAULT = 64;
-static inline int refill_auto(int64_t n) {
-    if (n < STG_REFILL_AUTO_ENVS) return 0;
-    const int64_t r = n / 65536;
-    return (int)(r > 8 ? 8 : r);
+static inline void refill_auto(int64_t n, int& r, int64_t& nw) {
+    r = 0; nw = 0;
+    if (n < STG_REFILL_AUTO_ENVS) return;
+    const int64_t nblk = (n + 63) / 64;
+    nw = 1024;
+    int64_t rr = (nblk + nw - 1) / nw;
+    if (rr > 8) { nw = 2048; rr = (nblk + nw - 1) / nw; }
+    r = (int)(rr > 1024 ? 1024 : rr);
 }
 constexpr int32_t STG_WALK_TILES_DEFAULT = 1 << 20;   // all tiles of the group (fastest, see stg_slot_block)
 
@@ -289,6 +294,7 @@ struct stg_ctx {
     uint8_t* env_type = nullptr;      // [N]: the device kind by itself, for the plan kernel (read in env order)
     bool per_env = false;
     int32_t walk_tiles = STG_WALK_TILES_DEFAULT;   // sorted schedule: tiles an XCD group keeps in flight (stg_slot_block)
+    int32_t hybrid = 1;                            // STG_HYBRID=0 switches the hybrid wave-specialised launch off (experiments)
     int32_t refill = -1, refill_check = STG_REFILL_CHECK_DEFAULT;        // STG_REFILL experiment override of cfg.lane_refill (-1: none)
 };
 
@@ -363,6 +369,7 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     if (!c) return fail(STG_E_NOMEM, "out of host memory");
     c->device = device_id; c->N = n_envs; c->env_id0 = env_id0; c->cfg = *cfg;
     c->walk_tiles = walk_tiles_from_env();
+    if (const char* e = std::getenv("STG_HYBRID")) c->hybrid = std::atoi(e);
     if (const char* e = std::getenv("STG_REFILL")) {
         int r = 0, chk = 0;
         if (std::sscanf(e, "%d,%d", &r, &chk) >= 1) { c->refill = r; if (chk > 0) c->refill_check = chk; }
@@ -570,17 +577,34 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
     a.force_wg1 = ctx->per_env ? 1 : 0;       // per-env rows fill the 64-row LDS block: 64 integrating lanes per workgroup
     // wave_spec: 0 = automatic (thermal launches of at most STG_WAVE_SPEC_MAX_ENVS envs, i.e. latency-bound ones),
     // 1 = always, -1 = never.  Results do not depend on it.
-    const bool pc = ctx->cfg.wave_spec > 0 || (ctx->cfg.wave_spec == 0 && ctx->N <= STG_WAVE_SPEC_MAX_ENVS);
+    bool pc = ctx->cfg.wave_spec > 0 || (ctx->cfg.wave_spec == 0 && ctx->N <= STG_WAVE_SPEC_MAX_ENVS);
+    // hybrid (RK45 + thermal, sorted schedule, 65 536 < N <= 131 072, automatic mode): producer/consumer pairs for the 1024 longest
+    // blocks, inline normals for the rest (stg_kernels.hpp: stg_hybrid_block); experiment knob STG_HYBRID=0/1
+    a.hybrid = 0;
+    if (ctx->cfg.solver == STG_SOLVER_RK45 && ctx->cfg.thermal && ctx->cfg.wave_spec == 0 && a.perm && !ctx->per_env &&
+        ctx->N > STG_WAVE_SPEC_MAX_ENVS && ctx->N <= 2 * STG_WAVE_SPEC_MAX_ENVS && ctx->hybrid != 0) {
+        // as many pairs as there are wave slots to spare: every wavefront of the launch is resident from the start
+        // (2048 slots at two wavefronts per SIMD; a launch of nblk blocks uses nblk of them for its integrating wavefronts)
+        const int64_t nblk = (ctx->N + 63) / 64;
+        int64_t n_pc = 2048 - nblk;
+        if (ctx->hybrid > 1) n_pc = ctx->hybrid;                 // STG_HYBRID=<pairs> (experiments)
+        n_pc = n_pc > 1024 ? 1024 : n_pc;
+        // (measured: 69 632 envs 2.87 -> 2.66 ms, 81 920 3.08 -> 2.87 ms; from 98 304 envs on the pairs cost more than they give)
+        if (n_pc >= 768 || ctx->hybrid > 1) { pc = true; a.hybrid = (int32_t)n_pc; }
+    }
     // lane refill (RK45 throughput launches, see stg_step_refill_kernel).  cfg.lane_refill: 0 = automatic, -1 never, >= 2 forced;
     // experiment knob STG_REFILL=<envs per lane>[,<attempts between refill points>] overrides the configuration
-    a.refill = 0; a.refill_check = STG_REFILL_CHECK_DEFAULT;
+    a.refill = 0; a.refill_check = STG_REFILL_CHECK_DEFAULT; a.refill_nw = 0;
     if (ctx->cfg.solver == STG_SOLVER_RK45 && K == 1 && !ctx->per_env && !ctx->cfg.skip_done) {
-        int r = ctx->cfg.lane_refill > 0 ? ctx->cfg.lane_refill : (ctx->cfg.lane_refill == 0 ? refill_auto(ctx->N) : 0);
-        int chk = STG_REFILL_CHECK_DEFAULT;
-        if (ctx->refill >= 0) { r = ctx->refill; chk = ctx->refill_check; }
+        const int64_t nblk = (ctx->N + 63) / 64;
+        int r = 0, chk = STG_REFILL_CHECK_DEFAULT;
+        int64_t nw = 0;
+        if (ctx->cfg.lane_refill == 0) refill_auto(ctx->N, r, nw);
+        else if (ctx->cfg.lane_refill > 0) { r = ctx->cfg.lane_refill; nw = (nblk + r - 1) / r; }
+        if (ctx->refill >= 0) { r = ctx->refill; chk = ctx->refill_check; nw = r >= 2 ? (nblk + r - 1) / r : 0; }
         // (not combined with the wave-specialised launch: a forced wave_spec = 1 keeps the one-env-per-lane kernel)
         if (r >= 2 && !(ctx->cfg.thermal && ctx->cfg.wave_spec > 0)) {
-            a.refill = r; a.refill_check = chk > 0 ? chk : STG_REFILL_CHECK_DEFAULT;
+            a.refill = r; a.refill_check = chk > 0 ? chk : STG_REFILL_CHECK_DEFAULT; a.refill_nw = (int32_t)nw;
             stg_dispatch_step_rk45_refill(a, ctx->cfg.thermal != 0, multi, ctx->axis_z_llgs, act_f64, st);
             HIP_TRY(hipGetLastError());
             return STG_OK;

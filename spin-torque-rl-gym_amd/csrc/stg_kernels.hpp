@@ -70,6 +70,9 @@ struct StepArgs {
     int32_t walk;                 // tiles of an XCD group in flight together (sorted schedule, see stg_slot_block)
     int32_t records;              // STG_OUT_RECORDS: `obs` is the record array [K or 1][N][STG_RECORD_BYTES], reward/term/trunc unused
     int32_t refill, refill_check; // lane-refill launch (stg_step_refill_kernel): envs per lane (rounds), attempts between refill points
+    int32_t refill_nw;            // ... and its number of wavefronts (queues); refill * refill_nw >= ceil(N / 64)
+    int32_t hybrid;               // wave-specialised launch: workgroups [0, hybrid) run as producer/consumer pairs, the others with the
+                                  // normals inline and no producer (0: every workgroup is a pair), see stg_hybrid_block
     const uint32_t* perm;         // lane -> env (duration-sorted schedule) or nullptr
     unsigned long long* counters; // [4]: env-steps, integrator sub-steps/attempts, RHS evaluations, no-op steps
     float* obs;                   // [K or 1][12][N]
@@ -336,6 +339,7 @@ constexpr int TILE_WAVES = TILE_ENVS / 64;             // = 64 wavefronts of the
 constexpr uint32_t STG_WALK_SNAKE_ON = 0x40000000u, STG_WALK_SNAKE_OFF = 0x20000000u;      // flag bits in `walk`
 template <int WGW>
 __device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool sorted, int cw, bool pairs, uint32_t walk) {
+    // (nwg: the workgroups of the batch, ceil(N / (WGW * 64)); the grid may hold up to 7 more, see step_grid)
     constexpr uint32_t TILE_WGS = TILE_WAVES / WGW;                   // workgroups per tile
     if (!sorted) return (int64_t)b * WGW + cw;
     if (WGW == 1 && pairs && nwg == 1024) {
@@ -348,11 +352,36 @@ __device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool
         const uint32_t r = b % 8, q = b / 8, g = q / 32, j = q % 32;
         return (int64_t)((g >> 1) * 8 + r) * TILE_WAVES + ((g & 1) ? (TILE_WAVES - 1 - j) : j);
     }
-    const uint32_t tiles8 = (nwg / (8 * TILE_WGS)) * 8;              // tiles in complete groups of 8
-    if (b >= tiles8 * TILE_WGS) return (int64_t)b * WGW + cw;
+    const uint32_t tiles = nwg / TILE_WGS;                            // complete tiles
+    {
+        // A ragged last tile (N no multiple of 4096) is sorted like the others, so its first workgroups are long ones: they go to
+        // the FRONT of the grid (round 3: at the end of the grid they started last -- 100 000 envs RK45 + thermal took 4.2 ms, more
+        // than 131 072), padded to a multiple of 8 workgroups so that the rest keeps its position modulo 8 (= its XCD).
+        const uint32_t part = nwg - tiles * TILE_WGS, pad = (part + 7u) & ~7u;
+        if (b < pad) return (int64_t)(tiles * TILE_WGS + (b < part ? b : nwg)) * WGW + cw;      // (padding workgroups: beyond N)
+        b -= pad;
+        if (b >= tiles * TILE_WGS) return (int64_t)nwg * WGW + cw;                                // (nothing left: beyond N)
+        nwg = tiles * TILE_WGS;
+    }
     const uint32_t r = b % 8;                                         // XCD group
     uint32_t q = b / 8;                                               // position inside the group
-    const uint32_t tiles_per_xcd = tiles8 / 8;
+    if (tiles % 8u != 0u) {
+        // Tile counts that are no multiple of 8 (round 3: until then the tiles beyond the last complete group of 8 kept the identity
+        // map at the END of the grid, so their longest wavefronts started last -- 81 920 envs RK45 + thermal took 4.9 ms, more than
+        // 131 072).  No tile-to-XCD affinity is possible here (the dispatcher deals the workgroups evenly over the XCDs, the tiles
+        // do not divide evenly), and with per-env records none is needed; what matters is the order: rank-major over ALL tiles
+        // (every tile's longest workgroup first), position o = q * 8 + r of that order, with the same boustrophedon rule per XCD
+        // group.  For tile counts that are multiples of 8 this formula IS the map below (u = q / tiles_per_xcd, t = (q %
+        // tiles_per_xcd) * 8 + r).
+        const uint32_t n_q = tiles * TILE_WGS / 8u, round = q / 32u, p = q % 32u;          // (TILE_WGS is a multiple of 8)
+        const bool snake = (walk & STG_WALK_SNAKE_ON) ? true : ((walk & STG_WALK_SNAKE_OFF) ? false : n_q <= 64u);
+        const uint32_t len = (n_q - round * 32u) < 32u ? (n_q - round * 32u) : 32u;
+        if (snake && (round & 1u)) q = round * 32u + (len - 1u - p);
+        const uint32_t o = q * 8u + r, u = o / tiles, t = o % tiles;
+        const uint32_t rank = (nwg <= 256) ? (u + TILE_WGS * cw) : (WGW * u + cw);
+        return (int64_t)t * TILE_WAVES + rank;
+    }
+    const uint32_t tiles_per_xcd = tiles / 8;
     {
         // Boustrophedon order over the XCD's 32 CUs.  The dispatcher deals a group's workgroups to its CUs in rounds of 32;
         // when every workgroup is resident from the start (at most two rounds: every kernel fits two workgroups per CU) the
@@ -376,6 +405,36 @@ __device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool
     // against 7.6 ms at 262 144 envs)
     const uint32_t rank = (nwg <= 256) ? (u + TILE_WGS * cw) : (WGW * u + cw);
     return (int64_t)t * TILE_WAVES + rank;
+}
+
+// 64-slot block `idx` of the longest-first order -> first slot: the blocks of a ragged last tile first (it is sorted like the
+// others, so it starts with long envs), then rank-major over the complete tiles (every tile's longest block, second longest, ...).
+__device__ __forceinline__ int64_t refill_slot_base(int64_t idx, int64_t tiles, int64_t nblk) {
+    const int64_t part = nblk - tiles * TILE_WAVES;
+    if (idx < part) return (tiles * TILE_WAVES + idx) * 64;
+    idx -= part;
+    const int64_t j = idx / tiles, t = idx - j * tiles;
+    return t * TILE_ENVS + j * 64;
+}
+
+// Hybrid wave-specialised launch (RK45 + thermal, 65 536 < N <= 131 072 envs, sorted schedule).  Such a launch is a makespan: it
+// ends with its longest wavefront, which runs nearly alone on its SIMD for most of the time -- and with the normals inline that
+// wavefront issues 725 instructions per attempt, with a producer 484.  There are wave slots for 1024 producers, not for 2048 (227
+// VGPRs: two wavefronts per SIMD), so only the LONGER HALF of the batch is wave-specialised: workgroups 0..1023 are
+// producer/consumer pairs over the 1024 longest 64-slot blocks of the rank-major order, workgroups 1024.. integrate the shorter
+// blocks with the normals inline (their second wavefront retires at once) and back-fill the slots that come free.
+// Placement of the pairs as in the 65 536-env launch (observed: workgroup b runs on XCD b % 8; a CU takes workgroups q, q+32, q+64,
+// q+96 of its XCD group; the producer of arrival g shares a SIMD with the integrating wavefront of arrival g+1): the arrivals of
+// a CU alternate between the long and the short end of its XCD's 128 blocks, so that every long integrating wavefront shares its
+// SIMD with the producer of a short one.  Speed heuristics only: results never depend on the schedule.
+__device__ __forceinline__ int64_t stg_hybrid_block(uint32_t b, uint32_t n_pc, int64_t tiles, int64_t nblk) {
+    int64_t k = b;                                                    // block of the rank-major order (longest first)
+    if (b < n_pc && n_pc == 1024u) {
+        const uint32_t r = b % 8u, q = b / 8u, g = q / 32u, j = q % 32u;
+        const uint32_t m = (g == 0u) ? j : (g == 1u) ? (127u - j) : (g == 2u) ? (32u + j) : (95u - j);
+        k = (int64_t)m * 8 + r;
+    }
+    return k < nblk ? refill_slot_base(k, tiles, nblk) : nblk * 64;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -507,7 +566,11 @@ __global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR st
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const bool producer = PC && wave >= WGW;
     const int cw = producer ? (2 * WGW - 1 - wave) : wave;          // the integrating wavefront this one is, or serves
-    const int64_t lane_slot = stg_slot_block<WGW>(blockIdx.x, gridDim.x, a.perm != nullptr, cw, PC, (uint32_t)a.walk) * 64 + lane;
+    // hybrid launch (PC kernels only): workgroups beyond a.hybrid have no producer and draw their normals inline
+    const bool paired = PC && (a.hybrid == 0 || blockIdx.x < (uint32_t)a.hybrid);
+    const int64_t lane_slot = ((PC && a.hybrid) ? stg_hybrid_block(blockIdx.x, (uint32_t)a.hybrid, a.N / TILE_ENVS, (a.N + 63) / 64)
+                                                : stg_slot_block<WGW>(blockIdx.x, (uint32_t)((a.N + WGW * 64 - 1) / (WGW * 64)), a.perm != nullptr, cw, PC,
+                                                                      (uint32_t)a.walk) * 64) + lane;
     const bool live = lane_slot < a.N;
     // duration-sorted schedule: slot j of the launch integrates env perm[j], so the 64 lanes of a wavefront have
     // (nearly) equal trip counts; all state and outputs stay at the env's own index
@@ -516,6 +579,7 @@ __global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR st
     // Lanes without an env: the one-wavefront form has no rendezvous after this point and lets them go; in the
     // wave-specialised form they stay (inert) because every wavefront of the workgroup takes part in every s_barrier.
     if (!PC && !live) return;
+    if (PC && !paired && (producer || !live)) return;               // (no rendezvous in an unpaired workgroup)
     const int64_t N = a.N;
     const uint64_t env_id = (uint64_t)(a.env_id0 + i);
 
@@ -558,7 +622,7 @@ __global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR st
         const bool lane_solves = live && !(a.c.skip_done && done);
         const RngKey rk{a.c.seed, env_id, rng};
         SolveOut so{m, 0, 0, 0, false};
-        if (PC) {
+        if (PC && paired) {
             // H1: this wavefront's stream positions and whether it integrates at all; then, if it does, H2 (chunk 0 is in
             // LDS, the handshake words are reset) and the solve (lanes that do not integrate are inert); inside the solve
             // the two wavefronts keep in step through the handshake words, not barriers
@@ -574,7 +638,7 @@ __global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR st
                 so = run_solver<SOLVER, THERMAL, false, AXIS_Z, DEVPHYS>(m, J, T, row, a.c, rk, norec, shared, lane_solves);
             }
         }
-        if (!PC && lane_solves) {
+        if (!(PC && paired) && lane_solves) {
             InlineNormals inl;
             so = run_solver<SOLVER, THERMAL, false, AXIS_Z, DEVPHYS>(m, J, T, row, a.c, rk, norec, inl, true);
         }
@@ -603,15 +667,6 @@ __global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR st
 //    action, the solve's prologue: two RHS calls, initial step) -- is lane-divergent code that the whole wavefront waits
 //    for; it is entered at most every `refill_check` attempts (lanes that finished within that window go together) or when
 //    no lane is integrating.
-// refill_block: 64-slot block `idx` of the rank-major order -> first slot.  Tiles beyond the complete ones: identity.
-__device__ __forceinline__ int64_t refill_slot_base(int64_t idx, int64_t tiles) {
-    if (idx < tiles * TILE_WAVES) {
-        const int64_t j = idx / tiles, t = idx - j * tiles;
-        return t * TILE_ENVS + j * 64;
-    }
-    return idx * 64;
-}
-
 template <bool THERMAL, bool MULTI, bool AXIS_Z, typename AT, int WGW>
 __global__ void __launch_bounds__(WGW * 64) stg_step_refill_kernel(const StepArgs a) {
     extern __shared__ double s_tab[];
@@ -624,7 +679,7 @@ __global__ void __launch_bounds__(WGW * 64) stg_step_refill_kernel(const StepArg
     }
     const int64_t N = a.N;
     const int R = a.refill;
-    const int64_t nblk = (N + 63) / 64, nw = (nblk + R - 1) / R, tiles = a.perm ? N / TILE_ENVS : 0;
+    const int64_t nblk = (N + 63) / 64, nw = a.refill_nw, tiles = N / TILE_ENVS;
     const int64_t w = (int64_t)blockIdx.x * WGW + wave;
     if (w >= nw) return;
     const AT* act = (const AT*)a.actions;
@@ -650,8 +705,9 @@ __global__ void __launch_bounds__(WGW * 64) stg_step_refill_kernel(const StepArg
     auto take = [&](int p, bool want) {
         const int r = p >> 6;
         const int64_t idx = (int64_t)r * nw + ((r & 1) ? (nw - 1 - w) : w);
-        const int64_t slot = refill_slot_base(idx, tiles) + (p & 63);
-        const bool valid = want && r < R && idx < nblk && slot < N;
+        const bool valid_blk = want && r < R && idx < nblk;
+        const int64_t slot = (valid_blk ? refill_slot_base(idx, tiles, nblk) : 0) + (p & 63);
+        const bool valid = valid_blk && slot < N;
         if (!valid) return;
         i = a.perm ? (int64_t)a.perm[slot] : slot;
         V3 m, tgt;
@@ -726,6 +782,15 @@ static size_t step_dyn_lds(const StepArgs& a) {
     return MULTI ? (size_t)(a.ep.soa ? 64 : a.ncls) * C_COUNT * sizeof(double) : 0;
 }
 
+// Grid of a step launch: the workgroups of the batch plus, under the sorted schedule, the padding that brings the ragged last
+// tile's workgroups (which go to the front of the grid, stg_slot_block) to a multiple of 8.
+static inline unsigned step_grid(const StepArgs& a, int wgw) {
+    const unsigned nwg = (unsigned)((a.N + wgw * 64 - 1) / (wgw * 64));
+    if (!a.perm) return nwg;
+    const unsigned tile_wgs = (unsigned)(TILE_WAVES / wgw), part = nwg % tile_wgs;
+    return nwg + (((part + 7u) & ~7u) - part);
+}
+
 // Workgroups of this kernel a CU holds at once (registers, LDS), asked of the runtime once per (kernel, LDS size) and thread.
 template <class KernelT>
 static int resident_workgroups_per_cu(KernelT kernel, int block, size_t lds) {
@@ -749,7 +814,7 @@ template <class KernelT>
 static StepArgs with_snake_rule(const StepArgs& a, KernelT kernel, int wgw, size_t lds, unsigned nwg) {
     StepArgs b = a;
     if (!a.perm || (a.walk & (int32_t)(STG_WALK_SNAKE_ON | STG_WALK_SNAKE_OFF))) return b;          // identity schedule / forced by STG_SNAKE
-    const unsigned tile_wgs = (unsigned)(TILE_WAVES / wgw), n_q = (nwg / (8u * tile_wgs)) * tile_wgs;   // workgroups per XCD group
+    const unsigned tile_wgs = (unsigned)(TILE_WAVES / wgw), n_q = (nwg / tile_wgs) * tile_wgs / 8u;     // workgroups per XCD group
     const int nb = resident_workgroups_per_cu(kernel, wgw * 64, lds);
     b.walk |= (int32_t)((n_q > 32u && n_q <= 32u * (unsigned)nb) ? STG_WALK_SNAKE_ON : STG_WALK_SNAKE_OFF);
     return b;
@@ -757,14 +822,15 @@ static StepArgs with_snake_rule(const StepArgs& a, KernelT kernel, int wgw, size
 
 template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, bool DEVPHYS, int WGW>
 static void launch_step_w(const StepArgs& a, int act_f64, bool pc, hipStream_t st) {
-    const dim3 grid((unsigned)((a.N + WGW * 64 - 1) / (WGW * 64)));
+    const dim3 grid(step_grid(a, WGW));
+    const unsigned nwg = (unsigned)((a.N + WGW * 64 - 1) / (WGW * 64));
     const size_t lds = step_dyn_lds<MULTI>(a);
     if (act_f64) {
         auto k = stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, double, false, WGW>;
-        hipLaunchKernelGGL(k, grid, dim3(WGW * 64), lds, st, with_snake_rule(a, k, WGW, lds, grid.x));
+        hipLaunchKernelGGL(k, grid, dim3(WGW * 64), lds, st, with_snake_rule(a, k, WGW, lds, nwg));
     } else {
         auto k = stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, float, false, WGW>;
-        hipLaunchKernelGGL(k, grid, dim3(WGW * 64), lds, st, with_snake_rule(a, k, WGW, lds, grid.x));
+        hipLaunchKernelGGL(k, grid, dim3(WGW * 64), lds, st, with_snake_rule(a, k, WGW, lds, nwg));
     }
 }
 
@@ -774,7 +840,7 @@ static void launch_step(const StepArgs& a, int act_f64, bool pc, hipStream_t st)
         // wave-specialised variant: one integrating + one producing wavefront per workgroup; not built for the
         // device-physics model
         constexpr bool PC = THERMAL && !DEVPHYS;
-        const dim3 grid((unsigned)((a.N + 63) / 64));
+        const dim3 grid(step_grid(a, 1));
         if (act_f64)
             hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, double, PC, 1>), grid, dim3(128), step_dyn_lds<MULTI>(a), st, a);
         else
@@ -809,7 +875,7 @@ static void dispatch_step(const StepArgs& a, bool thermal, bool multi, bool axis
 template <bool THERMAL, bool MULTI, bool AXIS_Z>
 static void launch_refill(const StepArgs& a, int act_f64, hipStream_t st) {
     constexpr int WGW = 4;
-    const int64_t nblk = (a.N + 63) / 64, nw = (nblk + a.refill - 1) / a.refill;
+    const int64_t nw = a.refill_nw;
     const dim3 grid((unsigned)((nw + WGW - 1) / WGW));
     const size_t lds = MULTI ? (size_t)a.ncls * C_COUNT * sizeof(double) : 0;
     if (act_f64) hipLaunchKernelGGL((stg_step_refill_kernel<THERMAL, MULTI, AXIS_Z, double, WGW>), grid, dim3(WGW * 64), lds, st, a);

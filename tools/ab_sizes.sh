@@ -7,9 +7,9 @@ for rep in $(seq $reps); do
 for lib in $LIBS; do
  for cfg in "${cfgs[@]}"; do
   set -- $cfg
-  env $ENVV STG_HIP_LIBRARY=$PWD/$lib python3 bench.py --steps 8 --warmup 2 --cpu-baseline 0 --also 0 --pmc off --solver rk45 --thermal $2 --envs-per-gpu $1 2>/dev/null | python3 -c "
+  env $ENVV STG_HIP_LIBRARY=$PWD/$lib python3 bench.py --steps 8 --warmup 2 --cpu-baseline 0 --also 0 --pmc off --solver ${SOLVER:-rk45} --thermal $2 --envs-per-gpu $1 2>/dev/null | python3 -c "
 import json,sys
-d=json.loads(sys.stdin.readline()); print('$(basename $lib) $ENVV rk45 n=$1 thermal=$2: kernel %.4f ms  (wall/step %.4f)' % (d['roofline']['kernel_ms_avg'], d['ms_per_step']))"
+d=json.loads(sys.stdin.readline()); print('$(basename $lib) $ENVV ${SOLVER:-rk45} n=$1 thermal=$2: kernel %.4f ms  (wall/step %.4f)' % (d['roofline']['kernel_ms_avg'], d['ms_per_step']))"
  done
 done
 done
