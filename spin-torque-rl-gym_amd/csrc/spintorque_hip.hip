@@ -294,6 +294,7 @@ struct stg_ctx {
     uint8_t* env_type = nullptr;      // [N]: the device kind by itself, for the plan kernel (read in env order)
     bool per_env = false;
     int32_t walk_tiles = STG_WALK_TILES_DEFAULT;   // sorted schedule: tiles an XCD group keeps in flight (stg_slot_block)
+    int32_t spread_max = 256;                      // STG_SPREAD_MAX (experiments), see StepArgs
     int32_t hybrid = 1;                            // STG_HYBRID=0 switches the hybrid wave-specialised launch off (experiments)
     int32_t refill = -1, refill_check = STG_REFILL_CHECK_DEFAULT;        // STG_REFILL experiment override of cfg.lane_refill (-1: none)
 };
@@ -370,6 +371,7 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     c->device = device_id; c->N = n_envs; c->env_id0 = env_id0; c->cfg = *cfg;
     c->walk_tiles = walk_tiles_from_env();
     if (const char* e = std::getenv("STG_HYBRID")) c->hybrid = std::atoi(e);
+    if (const char* e = std::getenv("STG_SPREAD_MAX")) c->spread_max = std::atoi(e);
     if (const char* e = std::getenv("STG_REFILL")) {
         int r = 0, chk = 0;
         if (std::sscanf(e, "%d,%d", &r, &chk) >= 1) { c->refill = r; if (chk > 0) c->refill_check = chk; }
@@ -569,6 +571,7 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
     a.actions = actions; a.K = K; a.out_every = out_every ? 1 : 0; a.autoreset = autoreset ? 1 : 0;
     a.records = records ? 1 : 0;
     a.walk = ctx->walk_tiles;
+    a.spread_max = ctx->spread_max;
     a.obs = obs; a.final_obs = final_obs; a.reward = reward; a.reward64 = reward_f64; a.energy = energy; a.term = terminated; a.trunc = truncated; a.status = status;
     // the Simple solver only draws a thermal field when temperature > 0 (simple_solver.py:321,378)
     const bool thermal = ctx->cfg.thermal && ctx->cfg.temperature > 0;

@@ -71,6 +71,8 @@ struct StepArgs {
     int32_t records;              // STG_OUT_RECORDS: `obs` is the record array [K or 1][N][STG_RECORD_BYTES], reward/term/trunc unused
     int32_t refill, refill_check; // lane-refill launch (stg_step_refill_kernel): envs per lane (rounds), attempts between refill points
     int32_t refill_nw;            // ... and its number of wavefronts (queues); refill * refill_nw >= ceil(N / 64)
+    int32_t spread_max;           // sorted schedule, 4-wavefront workgroups: up to this many workgroups a workgroup takes ranks u, u+16, u+32,
+                                  // u+48 of its tile (spread), beyond it four consecutive ranks (stg_slot_block)
     int32_t hybrid;               // wave-specialised launch: workgroups [0, hybrid) run as producer/consumer pairs, the others with the
                                   // normals inline and no producer (0: every workgroup is a pair), see stg_hybrid_block
     const uint32_t* perm;         // lane -> env (duration-sorted schedule) or nullptr
@@ -338,7 +340,7 @@ constexpr int TILE_WAVES = TILE_ENVS / 64;             // = 64 wavefronts of the
 //    a group at once = 363 MB of HBM traffic per launch for 42 MB of algorithmic bytes, see DESIGN.md section 3.
 constexpr uint32_t STG_WALK_SNAKE_ON = 0x40000000u, STG_WALK_SNAKE_OFF = 0x20000000u;      // flag bits in `walk`
 template <int WGW>
-__device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool sorted, int cw, bool pairs, uint32_t walk) {
+__device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool sorted, int cw, bool pairs, uint32_t walk, uint32_t spread_max = 256u) {
     // (nwg: the workgroups of the batch, ceil(N / (WGW * 64)); the grid may hold up to 7 more, see step_grid)
     constexpr uint32_t TILE_WGS = TILE_WAVES / WGW;                   // workgroups per tile
     if (!sorted) return (int64_t)b * WGW + cw;
@@ -353,6 +355,11 @@ __device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool
         return (int64_t)((g >> 1) * 8 + r) * TILE_WAVES + ((g & 1) ? (TILE_WAVES - 1 - j) : j);
     }
     const uint32_t tiles = nwg / TILE_WGS;                            // complete tiles
+    // One workgroup per CU at most (everything resident from the start, nobody shares a SIMD): a workgroup takes ranks u, u+16,
+    // u+32, u+48 of its tile (spread).  With more workgroups than CUs some CU holds two, wavefront w of both on the same SIMD: then
+    // a workgroup takes four consecutive ranks, so that the workgroups dispatched last are short throughout and whoever doubles up
+    // with them loses little (spread there puts a long wavefront into EVERY workgroup: 73 728 envs RK45 2.38 ms against 1.74 ms).
+    const bool spread = nwg <= spread_max;
     {
         // A ragged last tile (N no multiple of 4096) is sorted like the others, so its first workgroups are long ones: they go to
         // the FRONT of the grid (round 3: at the end of the grid they started last -- 100 000 envs RK45 + thermal took 4.2 ms, more
@@ -378,7 +385,7 @@ __device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool
         const uint32_t len = (n_q - round * 32u) < 32u ? (n_q - round * 32u) : 32u;
         if (snake && (round & 1u)) q = round * 32u + (len - 1u - p);
         const uint32_t o = q * 8u + r, u = o / tiles, t = o % tiles;
-        const uint32_t rank = (nwg <= 256) ? (u + TILE_WGS * cw) : (WGW * u + cw);
+        const uint32_t rank = spread ? (u + TILE_WGS * cw) : (WGW * u + cw);
         return (int64_t)t * TILE_WAVES + rank;
     }
     const uint32_t tiles_per_xcd = tiles / 8;
@@ -403,7 +410,7 @@ __device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool
     // one workgroup per CU at most (everything resident from the start): spread; otherwise keep wavefronts of similar
     // duration together, so that a workgroup's four SIMD slots come free together for the next one (measured 6.0 ms
     // against 7.6 ms at 262 144 envs)
-    const uint32_t rank = (nwg <= 256) ? (u + TILE_WGS * cw) : (WGW * u + cw);
+    const uint32_t rank = spread ? (u + TILE_WGS * cw) : (WGW * u + cw);
     return (int64_t)t * TILE_WAVES + rank;
 }
 
@@ -570,7 +577,7 @@ __global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR st
     const bool paired = PC && (a.hybrid == 0 || blockIdx.x < (uint32_t)a.hybrid);
     const int64_t lane_slot = ((PC && a.hybrid) ? stg_hybrid_block(blockIdx.x, (uint32_t)a.hybrid, a.N / TILE_ENVS, (a.N + 63) / 64)
                                                 : stg_slot_block<WGW>(blockIdx.x, (uint32_t)((a.N + WGW * 64 - 1) / (WGW * 64)), a.perm != nullptr, cw, PC,
-                                                                      (uint32_t)a.walk) * 64) + lane;
+                                                                      (uint32_t)a.walk, (uint32_t)a.spread_max) * 64) + lane;
     const bool live = lane_slot < a.N;
     // duration-sorted schedule: slot j of the launch integrates env perm[j], so the 64 lanes of a wavefront have
     // (nearly) equal trip counts; all state and outputs stay at the env's own index
