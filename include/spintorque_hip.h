@@ -124,7 +124,7 @@ typedef struct {
     double noise_corr_time;         /* correlation_time of ThermalFluctuations (default 1e-12 s); used when noise_model = 1 */
     int32_t lane_refill;            /* STG_SOLVER_RK45, single-step launches: every wavefront owns a queue of 64-env blocks of the sorted
                                        schedule and a lane that has finished its env takes the next one while its neighbours keep
-                                       integrating (ABI v3).  0 = automatic (launches of >= 196608 envs: 1024 queues -- one refill
+                                       integrating (ABI v3).  0 = automatic (launches of more than 131072 envs: 1024 queues -- one refill
                                        wavefront per SIMD -- up to 8 envs per lane, 2048 queues beyond), -1 = never, >= 2 = that many
                                        envs per lane.  Per-env arithmetic is untouched: results are bit-identical to the
                                        one-env-per-lane launch.  Not used with skip_done, per-env parameter records, fused steps

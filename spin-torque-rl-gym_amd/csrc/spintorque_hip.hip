@@ -257,15 +257,17 @@ static int fail(int code, const std::string& msg) {
             return fail(STG_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
     } while (0)
 
-// automatic lane refill of the RK45 step (measured on 196 608 ... 1 048 576 envs): from 196 608 envs, with
-// 1024 queues (one refill wavefront per SIMD; the 64-env blocks are dealt over them, so any batch size loads them evenly to within
-// one short block) while that leaves at most 8 envs per lane, else 2048 queues.  Below 3 envs per lane the refill launch has
-// nothing over the one-env-per-lane launch with its two wavefronts per SIMD.  Attempts between refill points: 64.
-constexpr int64_t STG_REFILL_AUTO_ENVS = 196608;
+// automatic lane refill of the RK45 step (measured on 132 000 ... 1 048 576 envs): above 131 072 envs, with 1024
+// queues (one refill wavefront per SIMD; the 64-env blocks are dealt over them, so any batch size loads them evenly to within one
+// short block) while that leaves at most 8 envs per lane, else 2048 queues.  At exactly two envs per lane (131 072 envs) the refill
+// launch has nothing over the one-env-per-lane launch with its two wavefronts per SIMD; just above, that launch needs a third
+// round of workgroups and the refill launch does not (132 000 envs: 4.36 -> 3.38 ms).  Attempts between refill points: 64.
+constexpr int64_t STG_REFILL_AUTO_ENVS = 131073;
 constexpr int32_t STG_REFILL_CHECK_DEFAULT = 64;
 static inline void refill_auto(int64_t n, int& r, int64_t& nw) {
     r = 0; nw = 0;
-    if (n < STG_REFILL_AUTO_ENVS) return;
+    static const int64_t min_envs = std::getenv("STG_REFILL_MIN") ? std::atoll(std::getenv("STG_REFILL_MIN")) : STG_REFILL_AUTO_ENVS;   // (experiments)
+    if (n < min_envs) return;
     const int64_t nblk = (n + 63) / 64;
     nw = 1024;
     int64_t rr = (nblk + nw - 1) / nw;

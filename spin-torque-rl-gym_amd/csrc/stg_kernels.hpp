@@ -763,16 +763,18 @@ __global__ void __launch_bounds__(WGW * 64) stg_step_refill_kernel(const StepArg
             V3 z2{0.0, 0.0, 0.0}, z3{0.0, 0.0, 0.0};
             llgs_lane_attempt<THERMAL, false, AXIS_Z>(L, out_m, k, tb, a.c.rtol, a.c.atol, a.c.max_step, norec, noek, ns, z2, z3);
         }
-        // ... then a refill point: finished lanes write their env and take entries q_next, q_next + 1, ... in lane order
+        // ... then a refill point: finished lanes write their env; every lane without an env -- finished just now, or one that drew an
+        // entry beyond N earlier (the ragged last block sits at the FRONT of the queue) -- takes entries q_next, q_next + 1, ... in lane order
         const bool fin = has_env && !L.active;
-        const unsigned long long finished = __ballot(fin);
-        if (finished != 0ull) {
+        const bool more = q_next < q_len;
+        if (__ballot(fin) != 0ull || (more && __ballot(!has_env) != 0ull)) {
             if (fin) finish();
-            const int rank = (int)__builtin_popcountll(finished & ((1ull << lane) - 1ull));
-            take(q_next + rank, fin && q_next + rank < q_len);
-            q_next += (int)__builtin_popcountll(finished);
+            const unsigned long long takers = __ballot(!has_env);
+            const int rank = (int)__builtin_popcountll(takers & ((1ull << lane) - 1ull));
+            take(q_next + rank, !has_env && q_next + rank < q_len);
+            q_next += (int)__builtin_popcountll(takers);
         }
-        if (__ballot(has_env) == 0ull) break;
+        if (__ballot(has_env) == 0ull && q_next >= q_len) break;
     }
     prof.stop(L.attempts);
     wave_add3(a.counters + (size_t)((blockIdx.x * WGW + wave) % COUNTER_STRIPES) * COUNTER_STRIDE, s_cnt + wave * 3, c_steps, c_sub, c_noop);

@@ -300,7 +300,7 @@ def test_cfg4_per_env_parameters_262144_vs_oracle_slices(stg):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# lane refill of the RK45 step (csrc/stg_kernels.hpp: stg_step_refill_kernel), automatic from 196 608 envs
+# lane refill of the RK45 step (csrc/stg_kernels.hpp: stg_step_refill_kernel), automatic above 131 072 envs
 # ------------------------------------------------------------------------------------------------------------------
 def test_lane_refill_rk45_thermal_262144_vs_oracle_slices_and_one_env_per_lane(stg):
     """VERDICT r2 item 2.  The headline workload at 262 144 envs takes the lane-refill kernel by default (4 envs per lane: a
