@@ -268,7 +268,7 @@ static inline void refill_auto(int64_t n, int& r, int64_t& nw) {
     r = 0; nw = 0;
     static const int64_t min_envs = std::getenv("STG_REFILL_MIN") ? std::atoll(std::getenv("STG_REFILL_MIN")) : STG_REFILL_AUTO_ENVS;   // (experiments)
     if (n < min_envs) return;
-    const int64_t nblk = (n + 63) / 64;
+    const int64_t nblk = ((n + TILE_ENVS - 1) / TILE_ENVS) * TILE_WAVES;      // blocks of whole tiles (a ragged tile's empty blocks included)
     nw = 1024;
     int64_t rr = (nblk + nw - 1) / nw;
     if (rr > 8) { nw = 2048; rr = (nblk + nw - 1) / nw; }
@@ -601,7 +601,7 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
     // experiment knob STG_REFILL=<envs per lane>[,<attempts between refill points>] overrides the configuration
     a.refill = 0; a.refill_check = STG_REFILL_CHECK_DEFAULT; a.refill_nw = 0;
     if (ctx->cfg.solver == STG_SOLVER_RK45 && K == 1 && !ctx->per_env && !ctx->cfg.skip_done) {
-        const int64_t nblk = (ctx->N + 63) / 64;
+        const int64_t nblk = ((ctx->N + TILE_ENVS - 1) / TILE_ENVS) * TILE_WAVES;
         int r = 0, chk = STG_REFILL_CHECK_DEFAULT;
         int64_t nw = 0;
         if (ctx->cfg.lane_refill == 0) refill_auto(ctx->N, r, nw);

@@ -339,9 +339,11 @@ constexpr int TILE_WAVES = TILE_ENVS / 64;             // = 64 wavefronts of the
 //    rank-major inside such a set (longest wavefronts of the set first): measured at 262 144 mixed envs, all 8 tiles of
 //    a group at once = 363 MB of HBM traffic per launch for 42 MB of algorithmic bytes, see DESIGN.md section 3.
 constexpr uint32_t STG_WALK_SNAKE_ON = 0x40000000u, STG_WALK_SNAKE_OFF = 0x20000000u;      // flag bits in `walk`
+// with STG_WALK_SNAKE_ON: the number of leading rounds the boustrophedon order applies to (bits 21..28; 0 = every round)
+constexpr uint32_t STG_WALK_ROUNDS_SHIFT = 21u, STG_WALK_ROUNDS_MASK = 0xFFu << STG_WALK_ROUNDS_SHIFT;
 template <int WGW>
 __device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool sorted, int cw, bool pairs, uint32_t walk, uint32_t spread_max = 256u) {
-    // (nwg: the workgroups of the batch, ceil(N / (WGW * 64)); the grid may hold up to 7 more, see step_grid)
+    // (nwg: the workgroups of the batch, ceil(N / (WGW * 64)); the grid holds whole tiles, see step_grid)
     constexpr uint32_t TILE_WGS = TILE_WAVES / WGW;                   // workgroups per tile
     if (!sorted) return (int64_t)b * WGW + cw;
     if (WGW == 1 && pairs && nwg == 1024) {
@@ -354,28 +356,27 @@ __device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool
         const uint32_t r = b % 8, q = b / 8, g = q / 32, j = q % 32;
         return (int64_t)((g >> 1) * 8 + r) * TILE_WAVES + ((g & 1) ? (TILE_WAVES - 1 - j) : j);
     }
-    const uint32_t tiles = nwg / TILE_WGS;                            // complete tiles
+    // A ragged last tile (N no multiple of 4096) is treated as a complete one whose slots beyond N are empty: the plan kernel sorts its
+    // envs into its first slots, so its real blocks sit at the low ranks and are dealt with the other tiles' long blocks (rank-major:
+    // early), while its empty blocks sit at the high ranks -- dispatched last, gone at once.  (Round 3, first attempt: the ragged
+    // tile's workgroups at the front of the grid, padded to 8 -- one extra workgroup upset the dispatcher's round structure that the
+    // boustrophedon order relies on: RK4 at T = 0 K 131 136 envs 0.39 ms against 0.28 ms at 131 072.  Before that: at the end of the
+    // grid, identity order -- its long wavefronts doubled up with other long ones: 100 000 envs RK45 + thermal 4.2 ms.)
+    const uint32_t tiles = (nwg + TILE_WGS - 1) / TILE_WGS;           // tiles, the ragged one included
     // One workgroup per CU at most (everything resident from the start, nobody shares a SIMD): a workgroup takes ranks u, u+16,
     // u+32, u+48 of its tile (spread).  With more workgroups than CUs some CU holds two, wavefront w of both on the same SIMD: then
     // a workgroup takes four consecutive ranks, so that the workgroups dispatched last are short throughout and whoever doubles up
     // with them loses little (spread there puts a long wavefront into EVERY workgroup: 73 728 envs RK45 2.38 ms against 1.74 ms).
     const bool spread = nwg <= spread_max;
-    {
-        // A ragged last tile (N no multiple of 4096) is sorted like the others, so its first workgroups are long ones: they go to
-        // the FRONT of the grid (round 3: at the end of the grid they started last -- 100 000 envs RK45 + thermal took 4.2 ms, more
-        // than 131 072), padded to a multiple of 8 workgroups so that the rest keeps its position modulo 8 (= its XCD).
-        const uint32_t part = nwg - tiles * TILE_WGS, pad = (part + 7u) & ~7u;
-        if (b < pad) return (int64_t)(tiles * TILE_WGS + (b < part ? b : nwg)) * WGW + cw;      // (padding workgroups: beyond N)
-        b -= pad;
-        if (b >= tiles * TILE_WGS) return (int64_t)nwg * WGW + cw;                                // (nothing left: beyond N)
-        nwg = tiles * TILE_WGS;
-    }
+    const uint32_t snake_rounds = (walk & STG_WALK_ROUNDS_MASK) >> STG_WALK_ROUNDS_SHIFT;
+    if (b >= tiles * TILE_WGS) return (int64_t)tiles * TILE_WAVES;    // (beyond the grid of step_grid: no env)
+    nwg = tiles * TILE_WGS;
     const uint32_t r = b % 8;                                         // XCD group
     uint32_t q = b / 8;                                               // position inside the group
     if (tiles % 8u != 0u) {
         // Tile counts that are no multiple of 8 (round 3: until then the tiles beyond the last complete group of 8 kept the identity
-        // map at the END of the grid, so their longest wavefronts started last -- 81 920 envs RK45 + thermal took 4.9 ms, more than
-        // 131 072).  No tile-to-XCD affinity is possible here (the dispatcher deals the workgroups evenly over the XCDs, the tiles
+        // map at the END of the grid, where their long wavefronts doubled up with other long ones -- 81 920 envs RK45 + thermal took
+        // 4.9 ms, more than 131 072).  No tile-to-XCD affinity is possible here (the dispatcher deals the workgroups evenly over the XCDs, the tiles
         // do not divide evenly), and with per-env records none is needed; what matters is the order: rank-major over ALL tiles
         // (every tile's longest workgroup first), position o = q * 8 + r of that order, with the same boustrophedon rule per XCD
         // group.  For tile counts that are multiples of 8 this formula IS the map below (u = q / tiles_per_xcd, t = (q %
@@ -383,7 +384,7 @@ __device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool
         const uint32_t n_q = tiles * TILE_WGS / 8u, round = q / 32u, p = q % 32u;          // (TILE_WGS is a multiple of 8)
         const bool snake = (walk & STG_WALK_SNAKE_ON) ? true : ((walk & STG_WALK_SNAKE_OFF) ? false : n_q <= 64u);
         const uint32_t len = (n_q - round * 32u) < 32u ? (n_q - round * 32u) : 32u;
-        if (snake && (round & 1u)) q = round * 32u + (len - 1u - p);
+        if (snake && (round & 1u) && (snake_rounds == 0u || round < snake_rounds)) q = round * 32u + (len - 1u - p);
         const uint32_t o = q * 8u + r, u = o / tiles, t = o % tiles;
         const uint32_t rank = spread ? (u + TILE_WGS * cw) : (WGW * u + cw);
         return (int64_t)t * TILE_WAVES + rank;
@@ -400,9 +401,9 @@ __device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool
         const uint32_t n_q = tiles_per_xcd * TILE_WGS, round = q / 32u, p = q % 32u;
         const bool snake = (walk & STG_WALK_SNAKE_ON) ? true : ((walk & STG_WALK_SNAKE_OFF) ? false : n_q <= 64u);
         const uint32_t len = (n_q - round * 32u) < 32u ? (n_q - round * 32u) : 32u;
-        if (snake && (round & 1u)) q = round * 32u + (len - 1u - p);
+        if (snake && (round & 1u) && (snake_rounds == 0u || round < snake_rounds)) q = round * 32u + (len - 1u - p);
     }
-    walk &= ~(STG_WALK_SNAKE_ON | STG_WALK_SNAKE_OFF);
+    walk &= ~(STG_WALK_SNAKE_ON | STG_WALK_SNAKE_OFF | STG_WALK_ROUNDS_MASK);
     const uint32_t W = walk < tiles_per_xcd ? (walk ? walk : 1u) : tiles_per_xcd;        // tiles walked together
     const uint32_t set = q / (W * TILE_WGS), within = q % (W * TILE_WGS);
     const uint32_t Ws = (tiles_per_xcd - set * W) < W ? (tiles_per_xcd - set * W) : W;   // (the last set may be smaller)
@@ -414,12 +415,9 @@ __device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool
     return (int64_t)t * TILE_WAVES + rank;
 }
 
-// 64-slot block `idx` of the longest-first order -> first slot: the blocks of a ragged last tile first (it is sorted like the
-// others, so it starts with long envs), then rank-major over the complete tiles (every tile's longest block, second longest, ...).
-__device__ __forceinline__ int64_t refill_slot_base(int64_t idx, int64_t tiles, int64_t nblk) {
-    const int64_t part = nblk - tiles * TILE_WAVES;
-    if (idx < part) return (tiles * TILE_WAVES + idx) * 64;
-    idx -= part;
+// 64-slot block `idx` of the longest-first order -> first slot: rank-major over the tiles, a ragged last tile included (every tile's
+// longest block, second longest, ...; the ragged tile's blocks beyond N are empty).  idx < tiles * 64.
+__device__ __forceinline__ int64_t refill_slot_base(int64_t idx, int64_t tiles) {
     const int64_t j = idx / tiles, t = idx - j * tiles;
     return t * TILE_ENVS + j * 64;
 }
@@ -434,14 +432,14 @@ __device__ __forceinline__ int64_t refill_slot_base(int64_t idx, int64_t tiles, 
 // q+96 of its XCD group; the producer of arrival g shares a SIMD with the integrating wavefront of arrival g+1): the arrivals of
 // a CU alternate between the long and the short end of its XCD's 128 blocks, so that every long integrating wavefront shares its
 // SIMD with the producer of a short one.  Speed heuristics only: results never depend on the schedule.
-__device__ __forceinline__ int64_t stg_hybrid_block(uint32_t b, uint32_t n_pc, int64_t tiles, int64_t nblk) {
+__device__ __forceinline__ int64_t stg_hybrid_block(uint32_t b, uint32_t n_pc, int64_t tiles) {
     int64_t k = b;                                                    // block of the rank-major order (longest first)
     if (b < n_pc && n_pc == 1024u) {
         const uint32_t r = b % 8u, q = b / 8u, g = q / 32u, j = q % 32u;
         const uint32_t m = (g == 0u) ? j : (g == 1u) ? (127u - j) : (g == 2u) ? (32u + j) : (95u - j);
         k = (int64_t)m * 8 + r;
     }
-    return k < nblk ? refill_slot_base(k, tiles, nblk) : nblk * 64;
+    return k < tiles * TILE_WAVES ? refill_slot_base(k, tiles) : tiles * TILE_ENVS;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -575,7 +573,7 @@ __global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR st
     const int cw = producer ? (2 * WGW - 1 - wave) : wave;          // the integrating wavefront this one is, or serves
     // hybrid launch (PC kernels only): workgroups beyond a.hybrid have no producer and draw their normals inline
     const bool paired = PC && (a.hybrid == 0 || blockIdx.x < (uint32_t)a.hybrid);
-    const int64_t lane_slot = ((PC && a.hybrid) ? stg_hybrid_block(blockIdx.x, (uint32_t)a.hybrid, a.N / TILE_ENVS, (a.N + 63) / 64)
+    const int64_t lane_slot = ((PC && a.hybrid) ? stg_hybrid_block(blockIdx.x, (uint32_t)a.hybrid, (a.N + TILE_ENVS - 1) / TILE_ENVS)
                                                 : stg_slot_block<WGW>(blockIdx.x, (uint32_t)((a.N + WGW * 64 - 1) / (WGW * 64)), a.perm != nullptr, cw, PC,
                                                                       (uint32_t)a.walk, (uint32_t)a.spread_max) * 64) + lane;
     const bool live = lane_slot < a.N;
@@ -686,7 +684,7 @@ __global__ void __launch_bounds__(WGW * 64) stg_step_refill_kernel(const StepArg
     }
     const int64_t N = a.N;
     const int R = a.refill;
-    const int64_t nblk = (N + 63) / 64, nw = a.refill_nw, tiles = N / TILE_ENVS;
+    const int64_t tiles = (N + TILE_ENVS - 1) / TILE_ENVS, nblk = tiles * TILE_WAVES, nw = a.refill_nw;   // (blocks of whole tiles)
     const int64_t w = (int64_t)blockIdx.x * WGW + wave;
     if (w >= nw) return;
     const AT* act = (const AT*)a.actions;
@@ -713,7 +711,7 @@ __global__ void __launch_bounds__(WGW * 64) stg_step_refill_kernel(const StepArg
         const int r = p >> 6;
         const int64_t idx = (int64_t)r * nw + ((r & 1) ? (nw - 1 - w) : w);
         const bool valid_blk = want && r < R && idx < nblk;
-        const int64_t slot = (valid_blk ? refill_slot_base(idx, tiles, nblk) : 0) + (p & 63);
+        const int64_t slot = (valid_blk ? refill_slot_base(idx, tiles) : 0) + (p & 63);
         const bool valid = valid_blk && slot < N;
         if (!valid) return;
         i = a.perm ? (int64_t)a.perm[slot] : slot;
@@ -791,13 +789,12 @@ static size_t step_dyn_lds(const StepArgs& a) {
     return MULTI ? (size_t)(a.ep.soa ? 64 : a.ncls) * C_COUNT * sizeof(double) : 0;
 }
 
-// Grid of a step launch: the workgroups of the batch plus, under the sorted schedule, the padding that brings the ragged last
-// tile's workgroups (which go to the front of the grid, stg_slot_block) to a multiple of 8.
+// Grid of a step launch: under the sorted schedule whole tiles (a ragged last tile counts as one, see stg_slot_block).
 static inline unsigned step_grid(const StepArgs& a, int wgw) {
     const unsigned nwg = (unsigned)((a.N + wgw * 64 - 1) / (wgw * 64));
     if (!a.perm) return nwg;
-    const unsigned tile_wgs = (unsigned)(TILE_WAVES / wgw), part = nwg % tile_wgs;
-    return nwg + (((part + 7u) & ~7u) - part);
+    const unsigned tile_wgs = (unsigned)(TILE_WAVES / wgw);
+    return ((nwg + tile_wgs - 1) / tile_wgs) * tile_wgs;
 }
 
 // Workgroups of this kernel a CU holds at once (registers, LDS), asked of the runtime once per (kernel, LDS size) and thread.
@@ -813,19 +810,25 @@ static int resident_workgroups_per_cu(KernelT kernel, int block, size_t lds) {
     return nb;
 }
 
-// The boustrophedon workgroup order (stg_slot_block) pays exactly when every workgroup of an XCD group is resident from the
-// start -- then the dispatcher's assignment to the 32 CUs is static and the plain longest-first order stacks the longest
-// workgroup of EVERY round on the first CUs.  Whether that is so depends on the kernel's occupancy: the T = 0 K fixed-step
-// kernels hold four workgroups of four wavefronts per CU (262 144 envs = four rounds, all resident: cfg4 0.532 -> 0.500 ms, RK4
-// at T = 0 K 0.54 -> 0.49 ms with the snake), the device-physics and thermal ones three or two (the later rounds go to whichever
-// CU frees up first, where longest-first is better: 0.73 -> 0.79 ms with the snake).  So the host asks the runtime.
+// The boustrophedon workgroup order (stg_slot_block) balances the rounds of workgroups that are resident from the start -- for
+// those the dispatcher's assignment to the 32 CUs of an XCD is static, and the plain longest-first order stacks the longest
+// workgroup of EVERY such round on the first CUs.  Later rounds go to whichever CU frees up first, where longest-first is the
+// better order.  How many rounds are resident is the kernel's occupancy: the T = 0 K fixed-step kernels hold four workgroups of
+// four wavefronts per CU (262 144 envs = four rounds, all resident: cfg4 0.532 -> 0.500 ms, RK4 at T = 0 K 0.54 -> 0.49 ms), the
+// device-physics and thermal ones three or two.  So the host asks the runtime and the boustrophedon applies to that many leading
+// rounds (a launch a little over two rounds keeps its first two balanced: RK4 + thermal 132 000 envs).
 template <class KernelT>
 static StepArgs with_snake_rule(const StepArgs& a, KernelT kernel, int wgw, size_t lds, unsigned nwg) {
     StepArgs b = a;
     if (!a.perm || (a.walk & (int32_t)(STG_WALK_SNAKE_ON | STG_WALK_SNAKE_OFF))) return b;          // identity schedule / forced by STG_SNAKE
-    const unsigned tile_wgs = (unsigned)(TILE_WAVES / wgw), n_q = (nwg / tile_wgs) * tile_wgs / 8u;     // workgroups per XCD group
+    const unsigned tile_wgs = (unsigned)(TILE_WAVES / wgw), n_q = ((nwg + tile_wgs - 1) / tile_wgs) * tile_wgs / 8u;   // workgroups per XCD group
     const int nb = resident_workgroups_per_cu(kernel, wgw * 64, lds);
-    b.walk |= (int32_t)((n_q > 32u && n_q <= 32u * (unsigned)nb) ? STG_WALK_SNAKE_ON : STG_WALK_SNAKE_OFF);
+    // ... while the launch is at most half a round over what is resident: with a whole further round of workgroups waiting, plain
+    // longest-first measured better throughout (cfg4 device-physics kernel, three of four rounds resident: 0.72 ms against 0.765;
+    // RK4 + thermal 262 144 envs, two of four: 1.47 against 1.51)
+    if (n_q > 32u && nb >= 2 && n_q <= 32u * (unsigned)nb + 16u)
+        b.walk |= (int32_t)(STG_WALK_SNAKE_ON | ((unsigned)(nb > 255 ? 255 : nb) << STG_WALK_ROUNDS_SHIFT));
+    else b.walk |= (int32_t)STG_WALK_SNAKE_OFF;
     return b;
 }
 
