@@ -340,6 +340,29 @@ def test_lane_refill_ragged_sizes_and_class_tables(stg, thermal):
         assert c0 == c1
 
 
+@pytest.mark.parametrize("solver,thermal,sizes", [
+    ("rk4", False, (4097, 65600, 66000, 69632, 81920, 100000, 131136, 132000, 165000, 200001, 262145)),
+    ("rk4", True, (66000, 100000, 132000)),
+    ("rk45", True, (65600, 66000, 81920, 100000, 131136, 132000, 165000)),      # wave-specialised / hybrid / one-env-per-lane / refill
+    ("rk45", False, (66000, 100000, 132000, 170000)),
+])
+def test_schedule_covers_every_env_once_at_odd_sizes(stg, solver, thermal, sizes):
+    """Round 3 rewrote the lane schedule for batch sizes that are no multiple of 8 tiles (32 768 envs) or of a tile (4096): rank-major
+    order over all tiles, the ragged tile as a partly empty one, spread / consecutive ranks by the total workgroup count,
+    boustrophedon on the resident rounds, hybrid producer/consumer launch up to 81 920 envs, lane refill above 131 072.  The
+    schedule must stay a permutation: every env stepped exactly once (on-device counter) and every output bit equal to the identity
+    schedule's (lane_sort=False, which also switches hybrid and refill queues to the identity order)."""
+    vol = 9.7e-6 if solver == "rk45" else 8.75e-11
+    for n in sizes:
+        m0, tgt, acts = _inputs(n, seed=n, steps=1, thi=3e-10)
+        kw = dict(device_params=stt_default_params(volume=vol), include_thermal_fluctuations=thermal, solver=solver, seed=3, autoreset=True,
+                  max_steps=1)
+        a, ca = _run_hip(stg, n, m0, tgt, acts, **kw)
+        b, cb = _run_hip(stg, n, m0, tgt, acts, lane_sort=False, **kw)
+        assert ca["env_steps"] == n and ca == cb, (solver, thermal, n, ca, cb)
+        _assert_same_bits(a, b, ("schedule", solver, thermal, n))
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # cfg 2: 4096 envs, T = 0 K, RK45 -- every env
 # ------------------------------------------------------------------------------------------------------------------
