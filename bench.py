@@ -490,6 +490,7 @@ def row_specs(args):
             ("cfg2: 4096 STT envs, T=0K, rk4 (the env's own solver)", 4096, "rk4", 0, False, "reference", False, False),
             ("cfg3: 65536 STT envs, thermal on, rk4", 65536, "rk4", 1, False, "reference", False, False),
             ("cfg5 shard: 131072 STT envs (1 048 576 over 8 GPUs), thermal on, rk45", 131072, "rk45", 1, False, "reference", False, False),
+            ("cfg5 on ONE GPU: 1048576 STT envs, thermal on, rk45 (lane-refill kernel: 8 envs per lane)", 1048576, "rk45", 1, False, "reference", False, False),
             ("cfg4: 262144 mixed STT/SOT/VCMA envs (class table in LDS), T=0K, rk4, reference RHS for all types",
              262144, "rk4", 0, True, "reference", False, False),
             ("cfg4: 262144 mixed STT/SOT/VCMA envs, T=0K, rk4, device-physics torque terms per type (opt-in)",

@@ -168,6 +168,8 @@ struct PlanArgs {
     const uint8_t* env_type;  // (per-env parameters: the kind of each env)
     int32_t by_kind;
     uint32_t* perm;
+    void* act_sorted;         // [N][2] in the actions' dtype, slot order: the step kernel reads its action with one coalesced load
+                              // instead of two scattered 4-byte reads through the permutation
 };
 
 __device__ __forceinline__ int plan_key(const PlanArgs& a, int64_t i) {
@@ -213,7 +215,12 @@ __global__ void __launch_bounds__(PLAN_THREADS) stg_plan_tile_kernel(const PlanA
 #pragma unroll
     for (int r = 0; r < PLAN_ITEMS; ++r) {
         const int64_t i = base + r * PLAN_THREADS + tid;
-        if (key[r] >= 0) a.perm[base + (start[key[r]] - cnt[key[r]]) + rank[r]] = (uint32_t)i;   // exclusive start
+        if (key[r] >= 0) {
+            const int64_t slot = base + (start[key[r]] - cnt[key[r]]) + rank[r];                   // exclusive start
+            a.perm[slot] = (uint32_t)i;
+            if (a.act_f64) ((double2*)a.act_sorted)[slot] = make_double2(((const double*)a.actions)[i], ((const double*)a.actions)[a.N + i]);
+            else ((float2*)a.act_sorted)[slot] = make_float2(((const float*)a.actions)[i], ((const float*)a.actions)[a.N + i]);
+        }
     }
 }
 
@@ -288,6 +295,7 @@ struct stg_ctx {
     const uint8_t* cls = nullptr;     // caller-owned device pointer
     unsigned long long* counters = nullptr;
     uint32_t* perm = nullptr;
+    void* act_sorted = nullptr;       // [N][2] actions of the step in slot order (written by the plan kernel)
     bool have_params = false, have_state = false;
     bool axis_z = false;              // every class has easy axis = +z exactly: the specialised Simple RHS applies
     bool axis_z_llgs = false;         // every class has raw easy axis (0,0,rz) and demag (0,0,Nz): specialised LLGS RHS
@@ -381,8 +389,8 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     // one slab: the state records, the class table, the counter stripes, the lane permutation (each 256-B aligned)
     auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
     const size_t N = (size_t)n_envs;
-    const size_t rs = al(N * sizeof(EnvRec)), r4 = al(N * 4);
-    const size_t total = rs + r4 + al(sizeof(double) * STG_MAX_CLASSES * C_COUNT) +
+    const size_t rs = al(N * sizeof(EnvRec)), r4 = al(N * 4), ra = al(N * 16);
+    const size_t total = rs + r4 + ra + al(sizeof(double) * STG_MAX_CLASSES * C_COUNT) +
                          COUNTER_STRIPES * COUNTER_STRIDE * sizeof(unsigned long long);
     hipError_t e = hipMalloc(&c->slab, total);
     if (e != hipSuccess) { delete c; return fail(STG_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
@@ -393,6 +401,7 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     c->ctab = (double*)p; p += al(sizeof(double) * STG_MAX_CLASSES * C_COUNT);
     c->counters = (unsigned long long*)p; p += COUNTER_STRIPES * COUNTER_STRIDE * sizeof(unsigned long long);
     c->perm = (uint32_t*)p; p += r4;
+    c->act_sorted = (void*)p; p += ra;
     *out = c;
     return STG_OK;
 }
@@ -562,13 +571,14 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
         pa.actions = actions; pa.act_f64 = act_f64; pa.N = ctx->N;
         pa.max_current = ctx->cfg.max_current; pa.max_duration = ctx->cfg.max_duration;
         pa.state = ctx->s.rec; pa.skip_done = (ctx->cfg.skip_done && !autoreset) ? 1 : 0;
-        pa.perm = ctx->perm;
+        pa.perm = ctx->perm; pa.act_sorted = ctx->act_sorted;
         pa.cls = ctx->cls; pa.ctab = ctx->ctab;
         pa.env_type = ctx->per_env ? ctx->env_type : nullptr;
         pa.by_kind = (ctx->cfg.torque_model == 1 && ((ctx->ncls > 1 && ctx->cls) || ctx->per_env)) ? 1 : 0;
         const dim3 g((unsigned)((ctx->N + TILE_ENVS - 1) / TILE_ENVS));
         hipLaunchKernelGGL(stg_plan_tile_kernel, g, dim3(PLAN_THREADS), 0, st, pa);
         a.perm = ctx->perm;
+        a.act_sorted = ctx->act_sorted;
     }
     a.actions = actions; a.K = K; a.out_every = out_every ? 1 : 0; a.autoreset = autoreset ? 1 : 0;
     a.records = records ? 1 : 0;

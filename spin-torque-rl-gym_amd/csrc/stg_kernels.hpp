@@ -76,6 +76,7 @@ struct StepArgs {
     int32_t hybrid;               // wave-specialised launch: workgroups [0, hybrid) run as producer/consumer pairs, the others with the
                                   // normals inline and no producer (0: every workgroup is a pair), see stg_hybrid_block
     const uint32_t* perm;         // lane -> env (duration-sorted schedule) or nullptr
+    const void* act_sorted;       // with perm: the first fused step's actions in slot order, [N][2] in their own dtype
     unsigned long long* counters; // [4]: env-steps, integrator sub-steps/attempts, RHS evaluations, no-op steps
     float* obs;                   // [K or 1][12][N]
     float* final_obs;             // [K or 1][12][N] (records: [K or 1][N][12]) or nullptr: terminal observation of envs auto-reset at that step
@@ -618,8 +619,15 @@ __global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR st
 
     for (int k = 0; k < a.K; ++k) {
         double J, T;
-        parse_action<AT>(act[((int64_t)k * 2 + 0) * N + i], act[((int64_t)k * 2 + 1) * N + i], a.c.max_current,
-                         a.c.max_duration, J, T);
+        if (k == 0 && a.perm) {
+            // slot order: one coalesced 8/16-byte load per lane (the plan kernel wrote it next to the permutation)
+            typedef typename std::conditional<std::is_same<AT, double>::value, double2, float2>::type AT2;
+            const AT2 aa = ((const AT2*)a.act_sorted)[live ? lane_slot : 0];
+            parse_action<AT>(aa.x, aa.y, a.c.max_current, a.c.max_duration, J, T);
+        } else {
+            parse_action<AT>(act[((int64_t)k * 2 + 0) * N + i], act[((int64_t)k * 2 + 1) * N + i], a.c.max_current,
+                             a.c.max_duration, J, T);
+        }
         const bool last = (k == a.K - 1);
         const int64_t ko = a.out_every ? k : 0;
         const bool wr = (a.out_every || last) && live;
@@ -698,6 +706,10 @@ __global__ void __launch_bounds__(WGW * 64) stg_step_refill_kernel(const StepArg
     int64_t i = 0;
     bool has_env = false;
     double J = 0.0, T = 0.0;
+    V3 e_tgt{0.0, 0.0, 1.0};                                    // the env's record as loaded (target, energy, step count, stream position)
+    double e_etot = 0.0;
+    int32_t e_step = 0;
+    uint32_t e_rng = 0;
     const double* row = a.ctab;
     LlgsK k = load_llgs(row);
     LlgsLane L;
@@ -715,13 +727,17 @@ __global__ void __launch_bounds__(WGW * 64) stg_step_refill_kernel(const StepArg
         const bool valid = valid_blk && slot < N;
         if (!valid) return;
         i = a.perm ? (int64_t)a.perm[slot] : slot;
-        V3 m, tgt;
-        double etot;
-        int32_t step;
-        uint32_t rng;
+        V3 m;
         bool done;
-        load_state(a.s, i, m, tgt, etot, step, rng, done);
-        parse_action<AT>(act[i], act[N + i], a.c.max_current, a.c.max_duration, J, T);
+        load_state(a.s, i, m, e_tgt, e_etot, e_step, e_rng, done);           // (kept for the tail of the env-step: no second read)
+        const uint32_t rng = e_rng;
+        if (a.perm) {
+            typedef typename std::conditional<std::is_same<AT, double>::value, double2, float2>::type AT2;
+            const AT2 aa = ((const AT2*)a.act_sorted)[slot];
+            parse_action<AT>(aa.x, aa.y, a.c.max_current, a.c.max_duration, J, T);
+        } else {
+            parse_action<AT>(act[i], act[N + i], a.c.max_current, a.c.max_duration, J, T);
+        }
         if (MULTI) {
             const int c = (int)a.cls[i];
             row = s_tab + (c < a.ncls ? c : 0) * C_COUNT;
@@ -735,12 +751,11 @@ __global__ void __launch_bounds__(WGW * 64) stg_step_refill_kernel(const StepArg
     // finishes the lane's env: the rest of the env-step after the solve, outputs, state
     auto finish = [&]() {
         const SolveOut so = llgs_lane_finish<false>(L, out_m, norec, noek, ns);
-        V3 m, tgt;
-        double etot;
-        int32_t step;
-        uint32_t rng;
-        bool done;
-        load_state(a.s, i, m, tgt, etot, step, rng, done);      // (m is the row the solve started from: L.m0)
+        V3 m = L.m0, tgt = e_tgt;                                // (the row the solve started from; the rest of the record from take())
+        double etot = e_etot;
+        int32_t step = e_step;
+        uint32_t rng = e_rng;
+        bool done = false;                                       // (without skip_done the flag is recomputed by the tail)
         env_step_tail(a, i, 0, true, true, true, row, (uint64_t)(a.env_id0 + i), m, tgt, etot, step, rng, done, J, T, so, c_steps, c_sub, c_noop);
         store_state(a.s, i, m, tgt, etot, step, rng, done);
         has_env = false;

@@ -324,6 +324,27 @@ def test_lane_refill_rk45_thermal_262144_vs_oracle_slices_and_one_env_per_lane(s
         assert c2 == c, (variant, c2, c)
 
 
+def test_lane_refill_rk45_thermal_1048576_vs_oracle_slices(stg):
+    """bench.py's "cfg5 on ONE GPU" row: 1 048 576 envs, RK45 + thermal, automatic lane refill with 2048 queues of 8 envs per lane:
+    oracle slices, and the same bits as the one-env-per-lane launch."""
+    n = 1048576
+    m0, tgt, acts = _inputs(n, seed=77, steps=1)
+    kw = dict(device_params=stt_default_params(volume=9.7e-6), include_thermal_fluctuations=True, temperature=300.0, solver="rk45",
+              seed=1234, autoreset=True)
+    starts = _slice_starts(n)
+    keep = torch.cat([torch.arange(s0, s0 + SLICE) for s0 in starts]).cuda()
+    hip, c = _run_hip(stg, n, m0, tgt, acts, keep=keep, **kw)
+    assert c["env_steps"] == n and c["noop_steps"] == 0
+    worst = 0.0
+    for j, s0 in enumerate(starts):
+        ora = _run_oracle_slice(stg, s0, m0, tgt, acts, **kw)
+        worst = max(worst, _cmp_slice(hip, ora, slice(j * SLICE, (j + 1) * SLICE), TOL_RK45, ("refill 1M", s0)))
+    print("lane refill (1048576, rk45 + thermal): worst |dm| vs oracle on slices =", worst)
+    other, c2 = _run_hip(stg, n, m0, tgt, acts, keep=keep, lane_refill=False, **kw)
+    _assert_same_bits(hip, other, "refill 1M vs one env per lane")
+    assert c2 == c
+
+
 @pytest.mark.parametrize("thermal", [False, True])
 def test_lane_refill_ragged_sizes_and_class_tables(stg, thermal):
     """Forced refill on sizes that are no multiple of anything (last block, last queue round and last tile incomplete; fewer
