@@ -127,8 +127,8 @@ typedef struct {
                                        integrating (ABI v3).  0 = automatic (launches of more than 131072 envs: 1024 queues -- one refill
                                        wavefront per SIMD -- up to 8 envs per lane, 2048 queues beyond), -1 = never, >= 2 = that many
                                        envs per lane.  Per-env arithmetic is untouched: results are bit-identical to the
-                                       one-env-per-lane launch.  Not used with skip_done, per-env parameter records, fused steps
-                                       (K > 1) or a forced wave_spec = 1. */
+                                       one-env-per-lane launch.  Not used with per-env parameter records, fused steps (K > 1) or a
+                                       forced wave_spec = 1. */
     int32_t reserved0;              /* must be 0 */
 } stg_config;
 

@@ -610,7 +610,7 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
     // lane refill (RK45 throughput launches, see stg_step_refill_kernel).  cfg.lane_refill: 0 = automatic, -1 never, >= 2 forced;
     // experiment knob STG_REFILL=<envs per lane>[,<attempts between refill points>] overrides the configuration
     a.refill = 0; a.refill_check = STG_REFILL_CHECK_DEFAULT; a.refill_nw = 0;
-    if (ctx->cfg.solver == STG_SOLVER_RK45 && K == 1 && !ctx->per_env && !ctx->cfg.skip_done) {
+    if (ctx->cfg.solver == STG_SOLVER_RK45 && K == 1 && !ctx->per_env) {
         const int64_t nblk = ((ctx->N + TILE_ENVS - 1) / TILE_ENVS) * TILE_WAVES;
         int r = 0, chk = STG_REFILL_CHECK_DEFAULT;
         int64_t nw = 0;

@@ -710,6 +710,7 @@ __global__ void __launch_bounds__(WGW * 64) stg_step_refill_kernel(const StepArg
     double e_etot = 0.0;
     int32_t e_step = 0;
     uint32_t e_rng = 0;
+    bool e_skip = false;
     const double* row = a.ctab;
     LlgsK k = load_llgs(row);
     LlgsLane L;
@@ -744,8 +745,10 @@ __global__ void __launch_bounds__(WGW * 64) stg_step_refill_kernel(const StepArg
             k = load_llgs(row);
         }
         const RngKey rk{a.c.seed, (uint64_t)(a.env_id0 + i), rng};
+        // with skip_done an env whose episode has ended is not integrated: it passes through the tail as inactive at the next refill point
+        e_skip = a.c.skip_done && done;
         llgs_lane_begin<THERMAL, false, AXIS_Z>(L, out_m, m, J, T, k, row[C_BETA], row[C_BETAP], a.c.rtol, a.c.atol, a.c.max_step, rk,
-                                                norec, noek, ns, true);
+                                                norec, noek, ns, !e_skip);
         has_env = true;
     };
     // finishes the lane's env: the rest of the env-step after the solve, outputs, state
@@ -755,8 +758,8 @@ __global__ void __launch_bounds__(WGW * 64) stg_step_refill_kernel(const StepArg
         double etot = e_etot;
         int32_t step = e_step;
         uint32_t rng = e_rng;
-        bool done = false;                                       // (without skip_done the flag is recomputed by the tail)
-        env_step_tail(a, i, 0, true, true, true, row, (uint64_t)(a.env_id0 + i), m, tgt, etot, step, rng, done, J, T, so, c_steps, c_sub, c_noop);
+        bool done = e_skip;                                      // (a stepped env's flag is recomputed by the tail)
+        env_step_tail(a, i, 0, true, true, !e_skip, row, (uint64_t)(a.env_id0 + i), m, tgt, etot, step, rng, done, J, T, so, c_steps, c_sub, c_noop);
         store_state(a.s, i, m, tgt, etot, step, rng, done);
         has_env = false;
         L.active = false;

@@ -32,6 +32,7 @@ for case in range(cases):
     budget = int(rng.choice([200000, 200000, 60]))           # 60: most solves run out of attempts -> STATUS_NOOP
     sort = [None, False][int(rng.integers(0, 2))]
     layout = ["records", "soa"][int(rng.integers(0, 2))]
+    skip = bool(rng.integers(0, 3) == 0)                     # skip_done (no auto-reset): finished envs are not stepped
     kw = dict(device_params=p0)
     cls = None
     if mixed:
@@ -54,14 +55,15 @@ for case in range(cases):
             os.environ["STG_REFILL"] = refill
         else:
             os.environ["STG_REFILL"] = "0"
-        env = stg.SpinTorqueVecEnv(n, include_thermal_fluctuations=thermal, solver="rk45", seed=11 + case, autoreset=True, max_steps=2,
+        env = stg.SpinTorqueVecEnv(n, include_thermal_fluctuations=thermal, solver="rk45", seed=11 + case, autoreset=not skip, skip_done=skip,
+                                   max_steps=1 if skip else 2,
                                    diagnostics=True, class_index=cls, wave_spec=False, lane_sort=sort, max_attempts=budget,
                                    out_layout=layout, **kw)
         env.reset(seed=case)
         rec = []
         for a in acts:
             o, rw, te, tr, info = env.step(a)
-            rec.append([t.clone() for t in (o, rw, te, tr, info["status"], info["reward_f64"], info["energy"], info["final_obs"])])
+            rec.append([t.clone() for t in (o, rw, te, tr, info["status"], info["reward_f64"], info["energy"]) + ((info["final_obs"],) if not skip else ())])
         st = env.get_state()
         rec.append([st[k].clone() for k in ("m", "target", "total_energy", "step_count", "rng_step")])
         c = env.backend.counters()
@@ -69,7 +71,7 @@ for case in range(cases):
         outs.append((rec, c))
     same = all(torch.equal(x, y) for s1, s2 in zip(outs[0][0], outs[1][0]) for x, y in zip(s1, s2)) and outs[0][1] == outs[1][1]
     noop = outs[0][1]["noop_steps"]
-    print(f"case {case}: n={n} R={r} check={chk} thermal={thermal} mixed={mixed} f64={f64} budget={budget} sort={sort} {layout}: "
+    print(f"case {case}: n={n} R={r} check={chk} thermal={thermal} mixed={mixed} f64={f64} budget={budget} sort={sort} {layout} skip_done={skip}: "
           f"{'identical' if same else 'DIFFERENT'} (noop steps {noop}) [{time.time() - t_start:.0f} s]", flush=True)
     bad += not same
 print("soak:", "ok" if not bad else f"{bad} cases differ")
