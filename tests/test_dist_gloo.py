@@ -88,9 +88,19 @@ def _worker(rank, world, port, n, steps, q):
         out5 = env5.step(loc, actions_are_local=True)[:4]
         assert all(torch.equal(x, y[:nr]) for x, y in zip(out5, rec[k + 1]))
     if rank == 0:
-        q.put(rec)
+        q.put(_to_numpy(rec))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _to_numpy(rec):
+    """By value through the queue: a torch tensor travels as a shared-memory handle that the receiver can only open while the
+    sending process is alive -- the worker may have exited by then (seen once as FileNotFoundError in the parent)."""
+    return [x.numpy().copy() if torch.is_tensor(x) else tuple(t.numpy().copy() for t in x) for x in rec]
+
+
+def _from_numpy(rec):
+    return [torch.from_numpy(x) if isinstance(x, np.ndarray) else tuple(torch.from_numpy(t) for t in x) for x in rec]
 
 
 def _inputs(n, steps):
@@ -115,7 +125,7 @@ def test_two_rank_sharded_env_equals_single_process(oracle_mod):
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, steps, q)) for r in range(world)]
     for p in procs:
         p.start()
-    rec = q.get(timeout=240)
+    rec = _from_numpy(q.get(timeout=240))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -167,7 +177,7 @@ def _subgroup_worker(rank, world, port, n, steps, q):
             assert all(torch.equal(x, y) for x, y in zip(outs["all_gather"][k], outs["p2p"][k]))
             assert all(torch.equal(x[:n - 1], y) for x, y in zip(outs["all_gather"][k], outs["ragged"][k]))
         if rank == members[0]:
-            q.put(outs["p2p"])
+            q.put(_to_numpy(outs["p2p"]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -184,7 +194,7 @@ def test_sharded_env_on_a_subgroup_addresses_peers_by_global_rank(oracle_mod):
     procs = [ctx.Process(target=_subgroup_worker, args=(r, world, port, n, steps, q)) for r in range(world)]
     for p in procs:
         p.start()
-    rec = q.get(timeout=240)
+    rec = _from_numpy(q.get(timeout=240))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
