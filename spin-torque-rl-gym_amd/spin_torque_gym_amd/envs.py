@@ -55,6 +55,8 @@ class _Box:
         x = np.asarray(x)
         return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
 
+    __contains__ = contains           # `obs in env.observation_space`, as with gymnasium.spaces.Box
+
 
 def _box(low, high, shape=None, dtype=np.float32):
     if _spaces is not None:
