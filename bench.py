@@ -108,6 +108,8 @@ def parse_args():
                     "rehearse the multi-rank code path on a single GPU)")
     ap.add_argument("--gather-algo", default="all_gather", choices=["all_gather", "p2p"],
                     help="N > 1: RCCL all-gather (default) or the one-shot point-to-point exchange")
+    ap.add_argument("--sweep-timeout", type=float, default=120.0,
+                    help="N > 1: seconds the exchange sweep (all_gather / in-place / p2p by themselves) may take before it is abandoned")
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"],
                     help="auto: collect the hardware counters live with rocprofv3 child passes (N = 1 only)")
     ap.add_argument("--pmc-dump", default=None, help="write the per-row counter table (JSON) here as well")
@@ -891,7 +893,23 @@ def main():
             # the in-place all-gather and the point-to-point exchange below have never run over RCCL with N > 1 (one-GPU build
             # boxes): a safety copy of the measured line goes to stderr first, in case one of them does not come back
             print("bench.py (before the exchange sweep): " + json.dumps(dict(out, **block_report_of(meas))), file=sys.stderr, flush=True)
-        out["gather_only"]["all_algos_ms"] = gather_only_all_algos(n_local, args.solver, args.thermal, args.steps, rank, world, local_rank)
+        # ... and a watchdog on every rank: if the sweep hangs, rank 0 still prints the measured line (with the sweep marked as not
+        # finished) and every rank leaves with exit code 0 instead of sitting in a wedged collective until the launcher's timeout
+        def _sweep_timed_out():
+            if rank == 0:
+                out["gather_only"]["all_algos_ms"] = {"error": f"the exchange sweep did not finish within {args.sweep_timeout:g} s and was abandoned"}
+                out["cpu_baseline"] = None
+                out.update(block_report_of(meas, order=("block_throttled", "block_walls_ms", "blocks_timed")))
+                print(json.dumps(out), flush=True)
+            sys.stderr.flush()
+            os._exit(0)
+        import threading
+        dog = threading.Timer(args.sweep_timeout, _sweep_timed_out)
+        dog.daemon = True
+        dog.start()
+        sweep = gather_only_all_algos(n_local, args.solver, args.thermal, args.steps, rank, world, local_rank)
+        dog.cancel()
+        out["gather_only"]["all_algos_ms"] = sweep
     if rank == 0 and world == 1 and args.also:
         also = []
         for key, spec in specs[1:]:
