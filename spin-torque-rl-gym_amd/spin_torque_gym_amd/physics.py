@@ -27,8 +27,26 @@ from .devices import DeviceFactory, flatten_params
 MU0 = 4 * np.pi * 1e-7
 
 
-def _device_for(device_params: Dict[str, Any], device_type: str = "stt_mram"):
-    return DeviceFactory().create_device(device_type, device_params)
+class _RawParams:
+    """A bare device_params dict as the reference's solvers take it: they never build a device object, they read the dict
+    with `.get(key, default)` (simple_solver.py:126-131; llgs_solver.py:79-82,192-205), so a partial dict is legal there."""
+    device_type = "stt_mram"
+
+    def __init__(self, device_params: Dict[str, Any]):
+        self.device_params = device_params
+
+
+def _flat_for(device_params: Dict[str, Any], device_type: str = "stt_mram", validate: bool = True):
+    """The C-ABI parameter record of one solve.  validate: keep the outcome of the reference's `validate_parameters(params,
+    'stt_mram')` gate (RobustLLGSSolver: an invalid dict ends in the fallback result, robust_solver.py:108-110,140-150); the plain solvers
+    have no such gate."""
+    if device_type == "stt_mram":
+        p = flatten_params(_RawParams(device_params))
+    else:
+        p = flatten_params(DeviceFactory().create_device(device_type, device_params))
+    if not validate:
+        p.params_valid = 1
+    return p
 
 
 def _pulse_from_callable(current_func: Optional[Callable], t0: float, t1: float) -> float:
@@ -55,6 +73,7 @@ def _check_zero_field(field_func: Optional[Callable], t0: float, t1: float) -> N
 
 class _GpuSolverBase:
     _solver_name = "rk4"
+    _validate_params = False        # (RobustLLGSSolver turns the parameter gate on)
 
     def __init__(self, rtol, atol, max_step, gamma=2.21e5, device_index=0, backend=None, seed=0):
         self.rtol, self.atol, self.max_step, self.gamma = rtol, atol, max_step, gamma
@@ -69,7 +88,7 @@ class _GpuSolverBase:
                         temperature=float(temperature), gamma=self.gamma, max_step=self.max_step, rtol=self.rtol,
                         atol=self.atol, seed=self._seed)
         b = self._backend_factory(n, cfg, self.device_index, 0)
-        b.set_params([flatten_params(_device_for(device_params, device_type))])
+        b.set_params([_flat_for(device_params, device_type, self._validate_params)])
         return b
 
     def solve_batch(self, m_initial, current, duration, device_params: Dict[str, Any], thermal_noise: bool = False,
@@ -148,6 +167,7 @@ class SimpleLLGSSolver(_GpuSolverBase):
 
 class RobustLLGSSolver(SimpleLLGSSolver):
     """utils/robust_solver.py:22-345: same kernels (the gates are always on), reference constructor signature."""
+    _validate_params = True
 
     def __init__(self, method: str = "euler", rtol: float = 1e-3, atol: float = 1e-6, max_step: float = 1e-12,
                  timeout: float = 2.0, max_retries: int = 3, fallback_method: str = "euler",

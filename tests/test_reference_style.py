@@ -3,8 +3,13 @@
 Each test below follows one test of the reference (file:line given), with the same configuration dicts, actions and assertions,
 so that a maintainer of the reference recognises them: /root/reference/tests/integration/test_environment.py (API compliance :49-75,
 reset :77-93, determinism :95-123, episode length :125-142, reward bounds :144-163, device types :165-249, step rate :457-489) and
-/root/reference/tests/test_comprehensive_suite.py (|m| over random steps :106-127, zero-current energy :130-146, step / reset
-latency :375-411).  (The reference's main fixture passes an unsupported `reward_type` keyword, :31-38, so that class cannot run
+/root/reference/tests/test_comprehensive_suite.py (basic cycle :34-53, action / observation validation :55-100, |m| over random
+steps :106-127, zero-current energy :130-146, extreme actions :257-280 and :542-564, step / reset latency :375-411, solver |m|
+conservation :417-445, thermal-field statistics :447-476, a whole episode under a proportional policy :570-611) and the error
+handling of test_environment.py:531-584.  Not restated: `test_anisotropy_fields` (:478-498) asks the default-parameter env to
+respond to a 5e6 A/m^2 pulse -- with the default volume the reference's solver overflows and the env keeps the magnetisation
+(golden G3 holds the reference's own no-op outputs), so that test cannot pass on the reference either; the tests of
+utils/ modules outside the step path (cache, security, error statistics: SURVEY section 2, OUT OF SCOPE).  (The reference's main fixture passes an unsupported `reward_type` keyword, :31-38, so that class cannot run
 against the reference itself; the configuration used here is that fixture without it.)
 
 Two backends: the HIP library on the GPU (`-m gpu`) and the CPU oracle through the `backend=` test seam (`-m "not gpu"`), which
@@ -194,3 +199,102 @@ def test_step_and_reset_latency(make_env):
     reset_s = time.perf_counter() - t0
     assert step_s < 0.05, step_s
     assert reset_s < 0.1, reset_s
+
+
+def test_basic_environment_cycle(make_env):
+    """test_comprehensive_suite.py:34-53 (gym.make('SpinTorque-v0') = the class with its defaults, 100 steps)"""
+    env = make_env(max_steps=100)
+    obs, info = env.reset()
+    assert obs.shape == (12,) and isinstance(info, dict)
+    obs, reward, terminated, truncated, info = env.step(env.action_space.sample())
+    assert obs.shape == (12,)
+    assert isinstance(reward, (int, float)) and isinstance(terminated, bool) and isinstance(truncated, bool) and isinstance(info, dict)
+
+
+def test_action_space_validation(make_env):
+    """test_comprehensive_suite.py:55-72"""
+    env = make_env(max_steps=100)
+    env.reset()
+    for action in ([1e6, 1e-9], [0, 1e-12], [-1e6, 5e-9]):
+        obs, reward, done, trunc, info = env.step(action)
+        assert np.all(np.isfinite(obs)), "Observation contains non-finite values"
+        assert np.isfinite(reward), "Reward is non-finite"
+
+
+def test_observation_space_validation(make_env):
+    """test_comprehensive_suite.py:74-100"""
+    env = make_env(max_steps=100)
+    obs, info = env.reset()
+    assert abs(np.linalg.norm(obs[:3]) - 1.0) < 0.1
+    assert abs(np.linalg.norm(obs[3:6]) - 1.0) < 0.1
+    assert np.isfinite(obs[6]) and np.isfinite(obs[7])
+    assert 0 <= obs[8] <= 1
+
+
+def test_extreme_and_boundary_actions_are_handled(make_env):
+    """test_comprehensive_suite.py:257-280 ([1e15, 1e-15]) and :542-564 (boundary actions); test_environment.py:556-584
+    (very high current, negative duration, very long duration): never an exception, always finite outputs"""
+    params, _ = _DEVICE_CONFIGS["stt_mram"]
+    for kw in (dict(max_steps=100), dict(device_type="stt_mram", device_params=params, max_steps=50)):
+        env = make_env(**kw)
+        env.reset()
+        for action in ([1e15, 1e-15], [1e9, 1e-15], [-1e9, 10e-9], [0, 1e-9], np.array([1e20, 1e-9]), np.array([1e6, -1e-9]),
+                       np.array([0, 1e-3])):
+            obs, reward, done, trunc, info = env.step(action)
+            assert np.all(np.isfinite(obs)), f"Invalid observation with action {action}"
+            assert np.isfinite(reward), f"Invalid reward with action {action}"
+            if done or trunc:
+                env.reset()
+
+
+def test_full_training_episode(make_env):
+    """test_comprehensive_suite.py:570-611: a proportional policy for up to 100 steps; finite throughout, total reward > -1000"""
+    env = make_env(max_steps=100)
+    obs, info = env.reset()
+    total_reward, steps = 0.0, 0
+    while steps < 100:
+        alignment = float(np.dot(obs[:3], obs[3:6]))
+        obs, reward, done, trunc, info = env.step([2e6 * (1 - alignment), 1e-9])
+        total_reward += reward
+        steps += 1
+        assert np.all(np.isfinite(obs)) and np.isfinite(reward)
+        if done or trunc:
+            break
+    assert total_reward > -1000
+
+
+def test_invalid_device_type_and_missing_parameters(make_env):
+    """test_environment.py:531-554: constructor errors and their messages.  (The reference's test expects a ValueError for the missing
+    parameter; its factory re-raises every constructor error as RuntimeError("Failed to create ...: <message>"),
+    devices/device_factory.py:74-77, which is what the mirror does: the message is the one the test matches.)"""
+    with pytest.raises(ValueError, match="Unknown device type"):
+        make_env(device_type="invalid_device", device_params={}, max_steps=50)
+    with pytest.raises(RuntimeError, match="Missing required parameter"):
+        make_env(device_type="stt_mram", device_params={"volume": 1e-24}, max_steps=50)
+
+
+@pytest.mark.gpu
+def test_llgs_conservation_laws_on_gpu():
+    """test_comprehensive_suite.py:417-445: SimpleLLGSSolver().solve over 0.1 ns keeps |m| = 1 along the trajectory"""
+    from spin_torque_gym_amd.physics import SimpleLLGSSolver
+    solver = SimpleLLGSSolver()
+    m_initial = np.array([0.1, 0.2, 0.97])
+    m_initial = m_initial / np.linalg.norm(m_initial)
+    device_params = {'damping': 0.01, 'saturation_magnetization': 800e3, 'uniaxial_anisotropy': 1e6, 'volume': 1e-24,
+                     'easy_axis': np.array([0, 0, 1])}
+    result = solver.solve(m_initial, (0, 1e-10), device_params)
+    assert result['success'], f"Solver failed: {result.get('message')}"
+    magnitudes = np.linalg.norm(result['m'], axis=1)
+    assert np.all(np.abs(magnitudes - 1.0) < 0.01)
+
+
+def test_thermal_fluctuations_statistics():
+    """test_comprehensive_suite.py:447-476: ThermalFluctuations(300 K, seed 42): 1000 fields, unbiased, std = noise strength +-20 %"""
+    from spin_torque_gym_amd.physics import ThermalFluctuations
+    thermal = ThermalFluctuations(temperature=300.0, seed=42)
+    damping, ms, volume, dt = 0.01, 800e3, 1e-24, 1e-12
+    fields = np.array([thermal.generate_thermal_field(damping, ms, volume, dt) for _ in range(1000)])
+    mean_field, std_field = np.mean(fields, axis=0), np.std(fields, axis=0)
+    assert np.all(np.abs(mean_field) < 0.1 * np.mean(std_field)), "Thermal noise is biased"
+    theoretical_std = thermal.compute_noise_strength(damping, ms, volume)
+    assert np.all(np.abs(std_field - theoretical_std) < 0.2 * theoretical_std), "Thermal noise strength incorrect"
