@@ -298,3 +298,25 @@ def test_thermal_fluctuations_statistics():
     assert np.all(np.abs(mean_field) < 0.1 * np.mean(std_field)), "Thermal noise is biased"
     theoretical_std = thermal.compute_noise_strength(damping, ms, volume)
     assert np.all(np.abs(std_field - theoretical_std) < 0.2 * theoretical_std), "Thermal noise strength incorrect"
+
+
+def test_render_and_introspection_surface(make_env):
+    """spin_torque_env.py:556-745: render modes (None -> None, unknown -> ValueError, 'rgb_array' -> an image, or None with a warning
+    when Matplotlib is absent, as in the reference), analyze_episode / get_device_info / get_solver_info keys"""
+    import warnings
+    env = make_env(max_steps=100)
+    env.reset(seed=3)
+    assert env.render() is None
+    with pytest.raises(ValueError, match="Unsupported render mode"):
+        env.render("bogus")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        img = env.render("rgb_array")
+    assert img is None or (img.ndim == 3 and img.shape[2] == 3)
+    assert env.analyze_episode() == {}
+    env.step([0.0, 1e-10])
+    a = env.analyze_episode()
+    for key in ("total_energy", "final_alignment", "energy_efficiency", "history"):
+        assert key in a
+    assert "device_type" in env.get_device_info() or env.get_device_info()
+    assert {"method", "solve_count", "timeout_count"} <= set(env.get_solver_info())
