@@ -600,7 +600,7 @@ __global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR st
         for (int k = 0; k < a.K; ++k) {
             __syncthreads();                                       // H1: s_rng / s_go[k & 1] published
             const int p = (k & 1) * WGW;
-            if (!any_flag<WGW>(s_go + p)) continue;
+            if (!any_flag<WGW>(lds_flag(s_go + p))) continue;
             const RngKey rk{a.c.seed, env_id, s_rng[cw * 64 + lane]};
             produce_normals<NT, FIELD, DEPTH, BARRIER>(s_norm, s_hs, lane, rk, n_first, n_chunk, ghs);
         }
@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR st
             const bool mine = __ballot(lane_solves) != 0ull;
             s_go[p + cw] = mine ? 1 : 0;
             __syncthreads();                                       // H1
-            if ((WGW == 1) ? mine : any_flag<WGW>(s_go + p)) {
+            if ((WGW == 1) ? mine : any_flag<WGW>(lds_flag(s_go + p))) {
                 if (!BARRIER) s_hs[1] = 0;                         // (the producer is past its last read of the previous solve's value: H1)
                 __syncthreads();                                   // H2
                 so = run_solver<SOLVER, THERMAL, false, AXIS_Z, DEVPHYS>(m, J, T, row, a.c, rk, norec, shared, lane_solves);

@@ -314,8 +314,15 @@ constexpr int SHARED_SUBS3 = 4;          // sub-steps per chunk for the solvers 
 constexpr int PC_STOP = 1 << 30;
 constexpr int PC_SPIN_CAP = 1 << 22;
 
+// LDS words that both wavefronts of a pair touch are accessed through an LDS-typed volatile pointer: through a generic one the
+// compiler must keep a volatile access as a FLAT instruction (address-space inference does not rewrite volatile accesses), and a
+// flat store to LDS in front of the per-attempt barrier -- `flat_store_dword ... sc0 sc1; s_waitcnt vmcnt(0) lgkmcnt(0)` -- sits on
+// the integrating wavefront's critical path; typed, it is a `ds_write_b32`.
+typedef __attribute__((address_space(3))) int lds_int;
+__device__ __forceinline__ volatile lds_int* lds_flag(const int* p) { return (volatile lds_int*)p; }
+
 template <int WGW>
-__device__ __forceinline__ bool any_flag(volatile int* f) {
+__device__ __forceinline__ bool any_flag(volatile lds_int* f) {
     int v = f[0];
 #pragma unroll
     for (int j = 1; j < WGW; ++j) v |= f[j];
@@ -355,7 +362,7 @@ struct SharedNormalsT {
     __device__ __forceinline__ bool chunk_end(bool lane_continues) {
         const bool mine = __ballot(lane_continues) != 0ull;
         if (BARRIER) {
-            ((volatile int*)hs)[it & 1] = mine ? 1 : 0;
+            lds_flag(hs)[it & 1] = mine ? 1 : 0;
             __syncthreads();
             ++it;
             idx = 0;
@@ -403,7 +410,7 @@ __device__ __forceinline__ void produce_normals(T* buf, int* hs, int lane, const
         for (int k = 1;; ++k) {
             fill(k & 1, n_chunk);                      // chunk k, while the integrating wavefront works on chunk k - 1
             __syncthreads();                           // = the integrating wavefront's chunk_end rendezvous
-            if (((volatile int*)hs)[(k - 1) & 1] == 0) return;
+            if (lds_flag(hs)[(k - 1) & 1] == 0) return;
         }
     }
     for (int k = 1;; ++k) {
