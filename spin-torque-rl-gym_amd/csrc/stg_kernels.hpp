@@ -347,16 +347,6 @@ __device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool
     // (nwg: the workgroups of the batch, ceil(N / (WGW * 64)); the grid holds whole tiles, see step_grid)
     constexpr uint32_t TILE_WGS = TILE_WAVES / WGW;                   // workgroups per tile
     if (!sorted) return (int64_t)b * WGW + cw;
-    if (WGW == 1 && pairs && nwg == 1024) {
-        // Wave-specialised launch with exactly one integrating wavefront per SIMD (65 536 envs; 16 tiles, two per XCD
-        // group).  Observed placement (tools/probes/wave_placement.hip, 1024 x 128 threads): a CU takes the workgroups
-        // q, q+32, q+64, q+96 of its XCD group and the producer of arrival g shares a SIMD with the integrating
-        // wavefront of arrival g+1 (cyclically).  Arrivals alternate between the long half of a tile (ranks j) and the
-        // short half (ranks 63-j): every long integrating wavefront then shares its SIMD with the producer of a short
-        // one, which retires early, and its own producer runs next to a short integrating wavefront.
-        const uint32_t r = b % 8, q = b / 8, g = q / 32, j = q % 32;
-        return (int64_t)((g >> 1) * 8 + r) * TILE_WAVES + ((g & 1) ? (TILE_WAVES - 1 - j) : j);
-    }
     // A ragged last tile (N no multiple of 4096) is treated as a complete one whose slots beyond N are empty: the plan kernel sorts its
     // envs into its first slots, so its real blocks sit at the low ranks and are dealt with the other tiles' long blocks (rank-major:
     // early), while its empty blocks sit at the high ranks -- dispatched last, gone at once.  (Round 3, first attempt: the ragged
@@ -374,6 +364,23 @@ __device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool
     nwg = tiles * TILE_WGS;
     const uint32_t r = b % 8;                                         // XCD group
     uint32_t q = b / 8;                                               // position inside the group
+    if (WGW == 1 && pairs && tiles > 8u && tiles <= 16u && !(walk & STG_WALK_SNAKE_OFF)) {
+        // Wave-specialised launch with three or four workgroups per CU (32 768 < N <= 65 536 envs: 128-thread workgroups, everything
+        // resident at once).  Observed (tools/probes/wave_placement.hip, 513 ... 1024 x 128 threads; profiles/r03_pair_placement.txt):
+        // workgroup b runs on XCD b % 8, a CU takes the workgroups q, q+32, q+64, q+96 of its XCD group, and whatever the workgroup
+        // count the integrating wavefront of a CU's arrival g+1 shares its SIMD with the producer of arrival g (the last arrival's
+        // producer with the first arrival's integrating wavefront).  Even arrivals therefore take the long end of the group's share of
+        // the rank-major order and odd arrivals the short end: every long integrating wavefront shares its SIMD with the producer of a
+        // short one, which retires early, and its own producer runs next to a short integrating wavefront.  (Plain rank-major order:
+        // arrivals j, 256+j, 512+j, 768+j -- a long producer next to a three-quarter-length integrating wavefront: RK45 + thermal at
+        // 60 000 envs 2.40 ms against 2.14, RK4 + thermal 0.65 against 0.53.  At exactly 16 tiles the rule keeps each tile on one XCD
+        // group (position q of group r is block 8 q + r of the order = tile r or 8 + r); rounds 1-2 had a separate map for that size
+        // -- ranks j, 63-j of both tiles on CU j -- which this one replaces: RK45 the same, RK4 0.592 -> 0.559 ms.)
+        const uint32_t n_q = tiles * TILE_WGS / 8u, round = q / 32u, p = q % 32u;
+        q = (round & 1u) ? (n_q - 1u - ((round >> 1) * 32u + p)) : ((round >> 1) * 32u + p);
+        const uint32_t o = q * 8u + r, u = o / tiles, t = o % tiles;
+        return (int64_t)t * TILE_WAVES + u;
+    }
     if (tiles % 8u != 0u) {
         // Tile counts that are no multiple of 8 (round 3: until then the tiles beyond the last complete group of 8 kept the identity
         // map at the END of the grid, where their long wavefronts doubled up with other long ones -- 81 920 envs RK45 + thermal took

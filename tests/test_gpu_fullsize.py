@@ -363,8 +363,8 @@ def test_lane_refill_ragged_sizes_and_class_tables(stg, thermal):
 
 @pytest.mark.parametrize("solver,thermal,sizes", [
     ("rk4", False, (4097, 65600, 66000, 69632, 81920, 100000, 131136, 132000, 165000, 200001, 262145)),
-    ("rk4", True, (66000, 100000, 132000)),
-    ("rk45", True, (65600, 66000, 81920, 100000, 131136, 132000, 165000)),      # wave-specialised / hybrid / one-env-per-lane / refill
+    ("rk4", True, (33000, 40960, 50000, 61440, 65535, 66000, 100000, 132000)),          # (three / four producer-consumer workgroups per CU)
+    ("rk45", True, (32832, 36864, 45000, 60000, 65472, 65600, 66000, 81920, 100000, 131136, 132000, 165000)),      # wave-specialised / hybrid / one-env-per-lane / refill
     ("rk45", False, (66000, 100000, 132000, 170000)),
 ])
 def test_schedule_covers_every_env_once_at_odd_sizes(stg, solver, thermal, sizes):
