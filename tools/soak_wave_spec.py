@@ -7,7 +7,7 @@ from conftest import stt_default_params, vcma_default_params
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 2024)
 solvers = sys.argv[3].split(",") if len(sys.argv) > 3 else ["rk4", "euler", "rk45"]
 for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 36):
-    n = int(rng.choice([1, 63, 64, 65, 127, 129, 1000, 4097, 8191, 20000, 65535, 65536]))
+    n = int(rng.choice([1, 63, 64, 65, 127, 129, 1000, 4097, 8191, 20000, 33000, 40960, 50001, 61440, 65535, 65536]))
     solver = str(rng.choice(solvers))
     K = int(rng.integers(1, 4))
     mode = str(rng.choice(["plain", "skip_done", "autoreset"]))
