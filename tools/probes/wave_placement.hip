@@ -52,6 +52,13 @@ int main(int argc, char** argv) {
     printf("block(even wave) - block(odd wave) mod nblocks on shared SIMDs:");
     for (auto& kv : dh) printf(" %d:%d", kv.first, kv.second);
     printf("\n");
+    // any two wavefronts on one SIMD: histogram of the difference of their block ids (one-wavefront workgroups: which arrivals double up)
+    std::map<int,int> ph;
+    for (auto& kv : m) for (size_t x = 0; x < kv.second.size(); ++x) for (size_t y = x + 1; y < kv.second.size(); ++y)
+        ph[abs(kv.second[x].first - kv.second[y].first)]++;
+    printf("|block - block| of wavefront pairs sharing a SIMD:");
+    { int shown2 = 0; for (auto& kv : ph) if (shown2++ < 12) printf(" %d:%d", kv.first, kv.second); }
+    printf("\n");
     printf("SIMDs used: %zu\n", m.size());
     for (auto& kv : hist) printf("  SIMDs holding %d waves: %d\n", kv.first, kv.second);
     for (auto& kv : same_role) printf("  SIMDs with %d even-index waves out of %d: %d\n", kv.first / 10, kv.first % 10, kv.second);
