@@ -167,6 +167,7 @@ struct PlanArgs {
     const double* ctab;
     const uint8_t* env_type;  // (per-env parameters: the kind of each env)
     int32_t by_kind;
+    int32_t regroup;          // by_kind: renumber the tile's groups of four blocks longest-first (launches that are resident as a whole)
     uint32_t* perm;
     void* act_sorted;         // [N][2] in the actions' dtype, slot order: the step kernel reads its action with one coalesced load
                               // instead of two scattered 4-byte reads through the permutation
@@ -212,11 +213,52 @@ __global__ void __launch_bounds__(PLAN_THREADS) stg_plan_tile_kernel(const PlanA
         if (tid < nb) start[tid] += add;
         __syncthreads();
     }
+    // Grouped by device kind, the tile's slot sequence is one long-to-short ramp PER KIND, so its 64-slot blocks -- the step launch's
+    // wavefronts, dealt longest rank first -- are not in order of work (the longest block of the last kind has rank ~43).  GROUPS OF
+    // FOUR consecutive blocks (= one 4-wavefront workgroup of the step launch) are therefore renumbered by the pulse duration of their
+    // first env (stable): rank order becomes longest-first again, which is what the step kernel's schedule (stg_slot_block) assumes,
+    // while a workgroup's four wavefronts stay of one kind and of nearly one duration -- they have to finish together for their four
+    // SIMD slots to come free together, and a sub-step of one kind costs up to 1.5x that of another (renumbering single blocks mixed
+    // the kinds inside workgroups: 262 144 envs 0.72 -> 0.96 ms).  Only where it measured faster (tools/devphys_ab.py): launches of
+    // 98 304 ... 131 072 envs with 4-wavefront workgroups, i.e. one and a half to two workgroups per CU, which the boustrophedon order
+    // pairs long with short -- 131 072 envs 0.634 -> 0.508 ms, with the thermal field 1.51 -> 1.28 ms; 100 000 envs 0.623 -> 0.555 ms.
+    // Elsewhere the kind-major order is as good or better: up to 65 536 envs nothing shares a SIMD; at 70 000 envs the few workgroups
+    // of the second round land on the CUs holding the longest ones, which longest-first makes the costliest kind's (0.39 -> 0.60 ms);
+    // with more rounds than fit 262 144 envs 0.72 against 0.82 ms, 1 048 576 envs 2.30 against 2.47; per-env records (64-thread
+    // workgroups) 131 072 envs 0.557 against 0.745 ms.
+    __shared__ int grp_d[TILE_WAVES / 4];
+    __shared__ uint8_t grp_rank[TILE_WAVES / 4];
+    if (a.by_kind && a.regroup) {
+        constexpr int NG = TILE_WAVES / 4;
+        if (tid < NG) grp_d[tid] = 0x7fffffff;                 // (groups beyond N: last)
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < PLAN_ITEMS; ++r)
+            if (key[r] >= 0) {
+                const uint32_t sl = (start[key[r]] - cnt[key[r]]) + rank[r];
+                if ((sl & 255u) == 0u) grp_d[sl >> 8] = key[r] % PLAN_DUR;
+            }
+        __syncthreads();
+        // (a ragged tile's last, partly filled group keeps its place behind the full ones: the step kernel's "slot < N" test relies on
+        // the tile's envs filling its first slots)
+        const int64_t n_t = a.N - base < TILE_ENVS ? a.N - base : TILE_ENVS;
+        if (tid == (int)(n_t >> 8) && (n_t & 255)) grp_d[tid] = 0x7ffffffe;
+        __syncthreads();
+        if (tid < NG) {
+            const int d = grp_d[tid];
+            int before = 0;
+            for (int j = 0; j < NG; ++j) before += (grp_d[j] < d || (grp_d[j] == d && j < tid)) ? 1 : 0;
+            grp_rank[tid] = (uint8_t)before;
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int r = 0; r < PLAN_ITEMS; ++r) {
         const int64_t i = base + r * PLAN_THREADS + tid;
         if (key[r] >= 0) {
-            const int64_t slot = base + (start[key[r]] - cnt[key[r]]) + rank[r];                   // exclusive start
+            uint32_t sl = (start[key[r]] - cnt[key[r]]) + rank[r];                                 // exclusive start
+            if (a.by_kind && a.regroup) sl = ((uint32_t)grp_rank[sl >> 8] << 8) | (sl & 255u);
+            const int64_t slot = base + sl;
             a.perm[slot] = (uint32_t)i;
             if (a.act_f64) ((double2*)a.act_sorted)[slot] = make_double2(((const double*)a.actions)[i], ((const double*)a.actions)[a.N + i]);
             else ((float2*)a.act_sorted)[slot] = make_float2(((const float*)a.actions)[i], ((const float*)a.actions)[a.N + i]);
@@ -575,6 +617,8 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
         pa.cls = ctx->cls; pa.ctab = ctx->ctab;
         pa.env_type = ctx->per_env ? ctx->env_type : nullptr;
         pa.by_kind = (ctx->cfg.torque_model == 1 && ((ctx->ncls > 1 && ctx->cls) || ctx->per_env)) ? 1 : 0;
+        // (measured range, tools/devphys_ab.py: 4-wavefront workgroups, between one and a half and two workgroups per CU)
+        pa.regroup = (!ctx->per_env && ctx->N >= 98304 && ctx->N <= 131072 && !getenv("STG_NO_REGROUP")) ? 1 : 0;
         const dim3 g((unsigned)((ctx->N + TILE_ENVS - 1) / TILE_ENVS));
         hipLaunchKernelGGL(stg_plan_tile_kernel, g, dim3(PLAN_THREADS), 0, st, pa);
         a.perm = ctx->perm;

@@ -384,6 +384,24 @@ def test_schedule_covers_every_env_once_at_odd_sizes(stg, solver, thermal, sizes
         _assert_same_bits(a, b, ("schedule", solver, thermal, n))
 
 
+@pytest.mark.parametrize("thermal", [False, True])
+def test_device_physics_schedule_at_ragged_sizes(stg, thermal):
+    """The device-physics torque model groups the lanes of a tile by device kind and then renumbers the tile's 64-slot blocks by work
+    (plan kernel, launches of 98 304 ... 131 072 envs): workgroups stay type-uniform, rank order is longest-first.  A ragged tile's partly
+    filled group must keep its place (the step kernel's `slot < N` test): every env stepped exactly once and all bits equal to the identity
+    schedule's, at sizes that end inside a block, on a block boundary, on a tile boundary, and with random class assignments."""
+    for n, seed in ((4097, 1), (70001, 2), (98304, 3), (98304 + 64 * 7, 4), (100001, 5), (126999, 6), (131072, 7), (150017, 8)):   # (regrouped: 98 304 ... 131 072)
+        rng = np.random.default_rng(seed)
+        cls = rng.integers(0, 3, n).astype(np.uint8) if seed % 2 else (np.arange(n) % 3).astype(np.uint8)
+        m0, tgt, acts = _inputs(n, seed=n, steps=1, thi=4e-10)
+        kw = _cfg4_kwargs(stg, "device")
+        kw.update(include_thermal_fluctuations=thermal, max_steps=1)
+        a, ca = _run_hip(stg, n, m0, tgt, acts, cls=cls, **kw)
+        b, cb = _run_hip(stg, n, m0, tgt, acts, cls=cls, lane_sort=False, **kw)
+        assert ca["env_steps"] == n and ca == cb, (n, ca, cb)
+        _assert_same_bits(a, b, ("device-physics schedule", n, thermal))
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # cfg 2: 4096 envs, T = 0 K, RK45 -- every env
 # ------------------------------------------------------------------------------------------------------------------
