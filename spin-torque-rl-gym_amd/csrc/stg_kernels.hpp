@@ -550,7 +550,13 @@ template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, bool DEVPHYS, typen
 #ifndef STG_STEP_ATTR
 #define STG_STEP_ATTR
 #endif
-__global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64) STG_STEP_ATTR stg_step_kernel(const StepArgs a) {
+// (second bound = minimum wavefronts per SIMD: the fixed-step T = 0 K kernels with the reference RHS and the easy axis along z -- every
+// factory default -- sit at 127-129 VGPRs: one
+// register decides between three and four resident wavefronts per SIMD, so they are held to four: 127 VGPRs, no spills (cfg4 class
+// table 0.516 -> 0.505 ms, RK4 at T = 0 K 262 144 envs 0.513 -> 0.497 ms).  Not the class-table kernel with 64-thread workgroups (per-env
+// parameter records: its 23.5 KB LDS block per workgroup bounds the occupancy anyway, and the tighter allocation cost it 6 %).)
+__global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64, (SOLVER != STG_SOLVER_RK45 && !THERMAL && !DEVPHYS && AXIS_Z && !(MULTI && WGW == 1)) ? 4 : 1) STG_STEP_ATTR
+stg_step_kernel(const StepArgs a) {
     // the env-step arithmetic around the solver (energy, reward, flags) has no contraction: same roundings in every
     // instantiation, and the same as NumPy's
 #pragma clang fp contract(off)
