@@ -348,6 +348,7 @@ struct stg_ctx {
     int32_t walk_tiles = STG_WALK_TILES_DEFAULT;   // sorted schedule: tiles an XCD group keeps in flight (stg_slot_block)
     int32_t spread_max = 256;                      // STG_SPREAD_MAX (experiments), see StepArgs
     int32_t hybrid = 1;                            // STG_HYBRID=0 switches the hybrid wave-specialised launch off (experiments)
+    int32_t hybrid_min = 768;                      // fewest producer/consumer pairs for which the hybrid launch is used (STG_HYBRID_MIN)
     int32_t refill = -1, refill_check = STG_REFILL_CHECK_DEFAULT;        // STG_REFILL experiment override of cfg.lane_refill (-1: none)
 };
 
@@ -423,6 +424,7 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     c->device = device_id; c->N = n_envs; c->env_id0 = env_id0; c->cfg = *cfg;
     c->walk_tiles = walk_tiles_from_env();
     if (const char* e = std::getenv("STG_HYBRID")) c->hybrid = std::atoi(e);
+    if (const char* e = std::getenv("STG_HYBRID_MIN")) c->hybrid_min = std::atoi(e);
     if (const char* e = std::getenv("STG_SPREAD_MAX")) c->spread_max = std::atoi(e);
     if (const char* e = std::getenv("STG_REFILL")) {
         int r = 0, chk = 0;
@@ -637,21 +639,16 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
     // wave_spec: 0 = automatic (thermal launches of at most STG_WAVE_SPEC_MAX_ENVS envs, i.e. latency-bound ones),
     // 1 = always, -1 = never.  Results do not depend on it.
     bool pc = ctx->cfg.wave_spec > 0 || (ctx->cfg.wave_spec == 0 && ctx->N <= STG_WAVE_SPEC_MAX_ENVS);
-    // hybrid (RK45 + thermal, sorted schedule, 65 536 < N <= 131 072, automatic mode): producer/consumer pairs for the 1024 longest
-    // blocks, inline normals for the rest (stg_kernels.hpp: stg_hybrid_block); experiment knob STG_HYBRID=0/1
+    // hybrid (RK45 / RK4 + thermal, sorted schedule, 65 536 < N <= 131 072, automatic mode): 1024 two-wavefront workgroups -- producer /
+    // consumer pairs for the 2048 - nblk longest blocks, two blocks with inline normals in each of the others (stg_kernels.hpp:
+    // stg_hybrid_block); experiment knobs STG_HYBRID=0/1, STG_HYBRID_MIN=<fewest pairs worth it>
     a.hybrid = 0;
-    // (RK45: 69 632 envs 2.87 -> 2.66 ms; RK4 + thermal: 81 920 envs 0.74 -> 0.69 ms)
     if ((ctx->cfg.solver == STG_SOLVER_RK45 || (ctx->cfg.solver == STG_SOLVER_RK4 && thermal && !devphys)) &&
         ctx->cfg.thermal && ctx->cfg.wave_spec == 0 && a.perm && !ctx->per_env &&
         ctx->N > STG_WAVE_SPEC_MAX_ENVS && ctx->N <= 2 * STG_WAVE_SPEC_MAX_ENVS && ctx->hybrid != 0) {
-        // as many pairs as there are wave slots to spare: every wavefront of the launch is resident from the start
-        // (2048 slots at two wavefronts per SIMD; a launch of nblk blocks uses nblk of them for its integrating wavefronts)
-        const int64_t nblk = (ctx->N + 63) / 64;
-        int64_t n_pc = 2048 - nblk;
-        if (ctx->hybrid > 1) n_pc = ctx->hybrid;                 // STG_HYBRID=<pairs> (experiments)
-        n_pc = n_pc > 1024 ? 1024 : n_pc;
-        // (measured: 69 632 envs 2.87 -> 2.66 ms, 81 920 3.08 -> 2.87 ms; from 98 304 envs on the pairs cost more than they give)
-        if (n_pc >= 768 || ctx->hybrid > 1) { pc = true; a.hybrid = (int32_t)n_pc; }
+        const int64_t nblk = ((ctx->N + TILE_ENVS - 1) / TILE_ENVS) * TILE_WAVES;      // blocks of whole tiles: 1088 ... 2048
+        const int64_t n_pair = 2048 - nblk;
+        if (n_pair >= ctx->hybrid_min) { pc = true; a.hybrid = (int32_t)n_pair + 1; }
     }
     // lane refill (RK45 throughput launches, see stg_step_refill_kernel).  cfg.lane_refill: 0 = automatic, -1 never, >= 2 forced;
     // experiment knob STG_REFILL=<envs per lane>[,<attempts between refill points>] overrides the configuration

@@ -73,8 +73,9 @@ struct StepArgs {
     int32_t refill_nw;            // ... and its number of wavefronts (queues); refill * refill_nw >= ceil(N / 64)
     int32_t spread_max;           // sorted schedule, 4-wavefront workgroups: up to this many workgroups a workgroup takes ranks u, u+16, u+32,
                                   // u+48 of its tile (spread), beyond it four consecutive ranks (stg_slot_block)
-    int32_t hybrid;               // wave-specialised launch: workgroups [0, hybrid) run as producer/consumer pairs, the others with the
-                                  // normals inline and no producer (0: every workgroup is a pair), see stg_hybrid_block
+    int32_t hybrid;               // wave-specialised launch of 1024 workgroups over more than 1024 blocks: number of producer/consumer pairs + 1
+                                  // (the other workgroups integrate two blocks with the normals inline); 0: every workgroup is a pair.
+                                  // See stg_hybrid_block
     const uint32_t* perm;         // lane -> env (duration-sorted schedule) or nullptr
     const void* act_sorted;       // with perm: the first fused step's actions in slot order, [N][2] in their own dtype
     unsigned long long* counters; // [4]: env-steps, integrator sub-steps/attempts, RHS evaluations, no-op steps
@@ -430,24 +431,26 @@ __device__ __forceinline__ int64_t refill_slot_base(int64_t idx, int64_t tiles) 
     return t * TILE_ENVS + j * 64;
 }
 
-// Hybrid wave-specialised launch (RK45 + thermal, 65 536 < N <= 131 072 envs, sorted schedule).  Such a launch is a makespan: it
+// Hybrid wave-specialised launch (RK45 / RK4 + thermal, 65 536 < N <= 131 072 envs, sorted schedule).  Such a launch is a makespan: it
 // ends with its longest wavefront, which runs nearly alone on its SIMD for most of the time -- and with the normals inline that
-// wavefront issues 725 instructions per attempt, with a producer 484.  There are wave slots for 1024 producers, not for 2048 (227
-// VGPRs: two wavefronts per SIMD), so only the LONGER HALF of the batch is wave-specialised: workgroups 0..1023 are
-// producer/consumer pairs over the 1024 longest 64-slot blocks of the rank-major order, workgroups 1024.. integrate the shorter
-// blocks with the normals inline (their second wavefront retires at once) and back-fill the slots that come free.
-// Placement of the pairs as in the 65 536-env launch (observed: workgroup b runs on XCD b % 8; a CU takes workgroups q, q+32, q+64,
-// q+96 of its XCD group; the producer of arrival g shares a SIMD with the integrating wavefront of arrival g+1): the arrivals of
-// a CU alternate between the long and the short end of its XCD's 128 blocks, so that every long integrating wavefront shares its
-// SIMD with the producer of a short one.  Speed heuristics only: results never depend on the schedule.
-__device__ __forceinline__ int64_t stg_hybrid_block(uint32_t b, uint32_t n_pc, int64_t tiles) {
-    int64_t k = b;                                                    // block of the rank-major order (longest first)
-    if (b < n_pc && n_pc == 1024u) {
-        const uint32_t r = b % 8u, q = b / 8u, g = q / 32u, j = q % 32u;
-        const uint32_t m = (g == 0u) ? j : (g == 1u) ? (127u - j) : (g == 2u) ? (32u + j) : (95u - j);
-        k = (int64_t)m * 8 + r;
-    }
-    return k < tiles * TILE_WAVES ? refill_slot_base(k, tiles) : tiles * TILE_ENVS;
+// wavefront issues 725 instructions per RK45 attempt, with a producer 484.  There are 2048 wave slots (227 VGPRs: two wavefronts per
+// SIMD) and nblk > 1024 blocks, so not every block can have a producer; the launch is ALWAYS 1024 two-wavefront workgroups:
+//   * the n_pair = 2048 - nblk LONGEST blocks of the rank-major order run as producer/consumer pairs (one block per workgroup),
+//   * the other 2 (nblk - 1024) blocks two per workgroup, both wavefronts integrating with the normals inline.
+// Every wavefront is resident from the start and the dispatcher's arrival structure is that of the 65 536-env launch (stg_slot_block:
+// workgroup b on XCD b % 8, a CU takes q, q+32, q+64, q+96 of its group, wavefront 1 of arrival g shares its SIMD with wavefront 0 of
+// arrival g+1), so the same rule places the workgroups: ranked longest-first (pairs, then the two-block workgroups), even arrivals take
+// the long end of the group's share and odd arrivals the short end.  (Rounds 2-3 launched nblk workgroups -- the unpaired ones with a
+// second wavefront that retired at once -- which broke that structure beyond 1024 workgroups: 66 000 envs 2.60 ms.)
+// Speed heuristics only: results never depend on the schedule.
+// -> first slot of the block of wavefront `wave` (0 / 1) of workgroup b; `paired`: the workgroup is a producer/consumer pair
+__device__ __forceinline__ int64_t stg_hybrid_block(uint32_t b, int wave, uint32_t n_pair, int64_t tiles, bool& paired) {
+    const uint32_t r = b % 8u, q = b / 8u, round = q / 32u, p = q % 32u;            // 1024 workgroups: 128 per XCD group
+    const uint32_t qq = (round & 1u) ? (127u - ((round >> 1) * 32u + p)) : ((round >> 1) * 32u + p);
+    const uint32_t k = qq * 8u + r;                                                  // rank of the workgroup, longest first
+    paired = k < n_pair;
+    const int64_t blk = paired ? (int64_t)k : (int64_t)n_pair + 2 * (int64_t)(k - n_pair) + wave;
+    return blk < tiles * TILE_WAVES ? refill_slot_base(blk, tiles) : tiles * TILE_ENVS;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -579,15 +582,18 @@ stg_step_kernel(const StepArgs a) {
     static_assert(!PC || WGW == 1, "the wave-specialised form is one integrating + one producing wavefront");
     __shared__ NT s_norm[PC ? RING : 1];
     __shared__ int s_hs[2], s_go[2 * WGW];
-    __shared__ unsigned long long s_cnt[WGW * 3];
+    __shared__ unsigned long long s_cnt[(PC ? 2 : 1) * WGW * 3];    // (one triple per wavefront that may integrate)
     __shared__ uint32_t s_rng[PC ? WGW * 64 : 1];
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const bool producer = PC && wave >= WGW;
-    const int cw = producer ? (2 * WGW - 1 - wave) : wave;          // the integrating wavefront this one is, or serves
-    // hybrid launch (PC kernels only): workgroups beyond a.hybrid have no producer and draw their normals inline
-    const bool paired = PC && (a.hybrid == 0 || blockIdx.x < (uint32_t)a.hybrid);
-    const int64_t lane_slot = ((PC && a.hybrid) ? stg_hybrid_block(blockIdx.x, (uint32_t)a.hybrid, (a.N + TILE_ENVS - 1) / TILE_ENVS)
+    // hybrid launch (PC kernels only, a.hybrid = number of pairs + 1): the workgroups that are not pairs have no producer -- both their
+    // wavefronts integrate a block of their own with the normals inline (stg_hybrid_block)
+    bool paired = PC;
+    int64_t hyb_slot = 0;
+    if (PC && a.hybrid) hyb_slot = stg_hybrid_block(blockIdx.x, wave, (uint32_t)(a.hybrid - 1), (a.N + TILE_ENVS - 1) / TILE_ENVS, paired);
+    const bool producer = PC && paired && wave >= WGW;
+    const int cw = producer ? (2 * WGW - 1 - wave) : (wave < WGW ? wave : wave - WGW);   // the integrating wavefront this one is, or serves
+    const int64_t lane_slot = ((PC && a.hybrid) ? hyb_slot
                                                 : stg_slot_block<WGW>(blockIdx.x, (uint32_t)((a.N + WGW * 64 - 1) / (WGW * 64)), a.perm != nullptr, cw, PC,
                                                                       (uint32_t)a.walk, (uint32_t)a.spread_max) * 64) + lane;
     const bool live = lane_slot < a.N;
@@ -598,7 +604,7 @@ stg_step_kernel(const StepArgs a) {
     // Lanes without an env: the one-wavefront form has no rendezvous after this point and lets them go; in the
     // wave-specialised form they stay (inert) because every wavefront of the workgroup takes part in every s_barrier.
     if (!PC && !live) return;
-    if (PC && !paired && (producer || !live)) return;               // (no rendezvous in an unpaired workgroup)
+    if (PC && !paired && !live) return;                             // (no rendezvous in a workgroup that is not a pair)
     const int64_t N = a.N;
     const uint64_t env_id = (uint64_t)(a.env_id0 + i);
 
@@ -673,7 +679,8 @@ stg_step_kernel(const StepArgs a) {
     if (live) store_state(a.s, i, m, tgt, etot, step, rng, done);
     // on-device metrics (the reference's EnvironmentMonitor/solver stats are host-side bookkeeping): one atomic per
     // counter per wavefront, into one of COUNTER_STRIPES copies
-    wave_add3(a.counters + (size_t)((blockIdx.x * WGW + cw) % COUNTER_STRIPES) * COUNTER_STRIDE, s_cnt + cw * 3, c_steps, c_sub, c_noop);
+    const int ci = PC ? wave : cw;                                  // (this wavefront's counter triple)
+    wave_add3(a.counters + (size_t)((blockIdx.x * (PC ? 2 : 1) * WGW + ci) % COUNTER_STRIPES) * COUNTER_STRIDE, s_cnt + ci * 3, c_steps, c_sub, c_noop);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -883,7 +890,7 @@ static void launch_step(const StepArgs& a, int act_f64, bool pc, hipStream_t st)
         // wave-specialised variant: one integrating + one producing wavefront per workgroup; not built for the
         // device-physics model
         constexpr bool PC = THERMAL && !DEVPHYS;
-        const dim3 grid(step_grid(a, 1));
+        const dim3 grid(a.hybrid ? 1024u : step_grid(a, 1));          // (hybrid: always 1024 workgroups, see stg_hybrid_block)
         if (act_f64)
             hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, double, PC, 1>), grid, dim3(128), step_dyn_lds<MULTI>(a), st, a);
         else

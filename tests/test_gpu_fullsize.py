@@ -363,8 +363,8 @@ def test_lane_refill_ragged_sizes_and_class_tables(stg, thermal):
 
 @pytest.mark.parametrize("solver,thermal,sizes", [
     ("rk4", False, (4097, 65600, 66000, 69632, 81920, 100000, 131136, 132000, 165000, 200001, 262145)),
-    ("rk4", True, (33000, 40960, 50000, 61440, 65535, 66000, 100000, 132000)),          # (three / four producer-consumer workgroups per CU)
-    ("rk45", True, (32832, 36864, 45000, 60000, 65472, 65600, 66000, 81920, 100000, 131136, 132000, 165000)),      # wave-specialised / hybrid / one-env-per-lane / refill
+    ("rk4", True, (33000, 40960, 50000, 61440, 65535, 65537, 66000, 73729, 81920, 100000, 132000)),   # (three / four pair workgroups per CU; hybrid)
+    ("rk45", True, (32832, 36864, 45000, 60000, 65472, 65537, 65600, 66000, 69633, 77777, 81920, 81921, 100000, 131136, 132000, 165000)),      # wave-specialised / hybrid / one-env-per-lane / refill
     ("rk45", False, (66000, 100000, 132000, 170000)),
 ])
 def test_schedule_covers_every_env_once_at_odd_sizes(stg, solver, thermal, sizes):
@@ -382,6 +382,38 @@ def test_schedule_covers_every_env_once_at_odd_sizes(stg, solver, thermal, sizes
         b, cb = _run_hip(stg, n, m0, tgt, acts, lane_sort=False, **kw)
         assert ca["env_steps"] == n and ca == cb, (solver, thermal, n, ca, cb)
         _assert_same_bits(a, b, ("schedule", solver, thermal, n))
+
+
+@pytest.mark.parametrize("solver", ["rk45", "rk4"])
+def test_hybrid_launch_with_class_table_skip_done_and_fused_steps(stg, solver):
+    """The hybrid wave-specialised launch (65 536 < N <= 81 920 envs, thermal: 1024 two-wavefront workgroups, producer/consumer pairs for
+    the longest blocks, two blocks with inline normals in each of the others) with what the other tests of that size range leave out: a
+    class table (MULTI kernels), `skip_done` without auto-reset over two steps (finished envs are not integrated), K = 2 fused steps,
+    float64 actions.  Every env stepped the same number of times and all bits equal to the identity schedule's (which does not use it)."""
+    import torch
+    vol = 9.7e-6 if solver == "rk45" else 8.75e-11
+    fac = stg.DeviceFactory()
+    stt = fac.get_default_parameters("stt_mram"); stt["volume"] = vol
+    vc = fac.get_default_parameters("vcma_mram"); vc.update(polarization=0.6, volume=vol * 0.8)
+    for n in (65537, 70001, 81920):
+        cls = (np.arange(n) % 2).astype(np.uint8)
+        m0, tgt, acts = _inputs(n, seed=n + 1, steps=2, thi=2.5e-10)
+        kw = dict(device_type=["stt_mram", "vcma_mram"], device_params=[stt, vc], include_thermal_fluctuations=True, solver=solver, seed=5,
+                  max_steps=1, skip_done=True, autoreset=False)
+        a, ca = _run_hip(stg, n, m0, tgt, acts, cls=cls, **kw)
+        b, cb = _run_hip(stg, n, m0, tgt, acts, cls=cls, lane_sort=False, **kw)
+        assert ca == cb and ca["env_steps"] == n, (solver, n, ca, cb)          # (second step: every env is done and skipped)
+        _assert_same_bits(a, b, ("hybrid class table skip_done", solver, n))
+        # K = 2 fused steps, float64 actions
+        outs = []
+        for ls in (None, False):
+            env = stg.SpinTorqueVecEnv(n, diagnostics=True, class_index=cls, lane_sort=ls, **dict(kw, max_steps=100, skip_done=False, autoreset=True))
+            env.reset(options={"initial_state": m0, "target_state": tgt})
+            o, r, te, tr, info = env.step_many(torch.from_numpy(np.stack(acts).astype(np.float64)))
+            outs.append((o.clone(), r.clone(), te.clone(), tr.clone(), env.get_state()["m"].clone()))
+            env.close()
+        for x, y in zip(*outs):
+            assert torch.equal(x, y), (solver, n, "fused")
 
 
 @pytest.mark.parametrize("thermal", [False, True])
