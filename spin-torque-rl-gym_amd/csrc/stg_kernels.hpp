@@ -378,7 +378,10 @@ __device__ __forceinline__ int64_t stg_slot_block(uint32_t b, uint32_t nwg, bool
         // group (position q of group r is block 8 q + r of the order = tile r or 8 + r); rounds 1-2 had a separate map for that size
         // -- ranks j, 63-j of both tiles on CU j -- which this one replaces: RK45 the same, RK4 0.592 -> 0.559 ms.)
         const uint32_t n_q = tiles * TILE_WGS / 8u, round = q / 32u, p = q % 32u;
-        q = (round & 1u) ? (n_q - 1u - ((round >> 1) * 32u + p)) : ((round >> 1) * 32u + p);
+        // (the fourth arrival -- whose producer shares a SIMD with the FIRST arrival's integrating wavefront, the longest of the CU --
+        // takes the very shortest blocks, the second arrival the next shortest)
+        const uint32_t len3 = n_q > 96u ? n_q - 96u : 0u;                     // workgroups of the group's fourth round
+        q = (round == 0u) ? p : (round == 2u) ? (32u + p) : (round == 3u) ? (n_q - 1u - p) : (n_q - 1u - (len3 + p));
         const uint32_t o = q * 8u + r, u = o / tiles, t = o % tiles;
         return (int64_t)t * TILE_WAVES + u;
     }
@@ -446,7 +449,7 @@ __device__ __forceinline__ int64_t refill_slot_base(int64_t idx, int64_t tiles) 
 // -> first slot of the block of wavefront `wave` (0 / 1) of workgroup b; `paired`: the workgroup is a producer/consumer pair
 __device__ __forceinline__ int64_t stg_hybrid_block(uint32_t b, int wave, uint32_t n_pair, int64_t tiles, bool& paired) {
     const uint32_t r = b % 8u, q = b / 8u, round = q / 32u, p = q % 32u;            // 1024 workgroups: 128 per XCD group
-    const uint32_t qq = (round & 1u) ? (127u - ((round >> 1) * 32u + p)) : ((round >> 1) * 32u + p);
+    const uint32_t qq = (round == 0u) ? p : (round == 2u) ? (32u + p) : (round == 3u) ? (127u - p) : (95u - p);   // (as in stg_slot_block)
     const uint32_t k = qq * 8u + r;                                                  // rank of the workgroup, longest first
     paired = k < n_pair;
     const int64_t blk = paired ? (int64_t)k : (int64_t)n_pair + 2 * (int64_t)(k - n_pair) + wave;
