@@ -85,7 +85,9 @@ PMC_PASSES = {
     "write": "WRITE_SIZE",
 }
 PMC_TABLE = os.path.join(ROOT, "profiles", "r03_pmc_rows.json")
-MAIN_KERNELS = ("stg_step_kernel", "stg_step_refill_kernel", "stg_array_step_kernel", "stg_array_step_individual_kernel")
+# (prefixes: every env-step / array-step kernel of the library, whatever its variant is called -- a kernel missing from an explicit
+# list silently cost the whole counter table twice)
+MAIN_KERNELS = ("stg_step_", "stg_array_step_")
 MARKER_KERNEL = "stg_normals_kernel"
 
 

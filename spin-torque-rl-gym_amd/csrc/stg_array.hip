@@ -216,6 +216,156 @@ __global__ void __launch_bounds__(64) stg_array_step_kernel(const ArrArgs a) {
     a.trunc[i] = step >= a.max_steps ? 1 : 0;
 }
 
+// 'global' action mode on NDEV cells (4 x 4, the registered SpinTorqueArray-v0): every cell is addressed, in order.  The whole pattern
+// lives in REGISTERS (48 doubles) instead of a 24.6 KB per-wavefront copy in LDS: that copy bounded the general kernel at six
+// single-wavefront workgroups per CU (1.5 wavefronts per SIMD) for a launch that is a chain of 160 dependent normalise-and-step
+// iterations per lane -- latency-bound.  Registers cannot be indexed by the running cell, so the register file is ROTATED instead: at
+// the top of iteration d, pm[0] is cell d and pm[k] cell (d + k) mod n; after the update everything moves down one place (48 64-bit
+// moves per cell) and after n iterations it is back in place.  The coupling matrix is staged in LDS in that rotated order
+// (lc[d][k] = C[d][(d + k) mod n]), so a row is sixteen consecutive doubles.  All row accesses to the pattern / target / observation
+// arrays are BUFFER instructions: descriptor and row offset in scalar registers, one 32-bit lane offset in a VGPR -- no per-row 64-bit
+// VGPR addresses.  (A fully unrolled sweep, the other way to keep the pattern in registers, needed more than 340 of them: one
+// wavefront per SIMD.)  The coupling sum runs over the cells in rotated order (d+1, ..., n-1, 0, ..., d-1) instead of 0 ... n-1: the
+// only arithmetic difference to the general kernel, at the rounding level of a term that is ~1e-3 of the field.
+template <int NDEV>
+__global__ void __launch_bounds__(256, 3) stg_array_step_global_kernel(const ArrArgs a) {
+    extern __shared__ double lds[];           // rotated coupling [n][n]
+    constexpr int n = NDEV;
+    double* lc = lds;
+    if (a.include_coupling) {
+        for (int q = threadIdx.x; q < n * n; q += blockDim.x) {
+            const int d = q / n, k = q % n;
+            lc[q] = a.coupling[d * n + (d + k) % n];
+        }
+        __syncthreads();
+    }
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.N) return;
+    const int64_t N = a.N;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const uint32_t off8 = (uint32_t)i * 8u, off4 = (uint32_t)i * 4u;
+    const uint32_t row8 = (uint32_t)N * 8u, row4 = (uint32_t)N * 4u;
+    const int obs_rows = 6 * n + (a.obs_mode == 1 ? 4 : 0);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)a.pattern, 0, (int)(3u * n * row8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)a.target, 0, (int)(3u * n * row8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)a.obs, 0, (int)((uint32_t)obs_rows * row4), 0x00020000);
+    auto ldp = [&](int row) -> double { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rp, off8, (uint32_t)row * row8, 0)); };
+    auto ldt = [&](int row) -> double { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rt, off8, (uint32_t)row * row8, 0)); };
+    auto stp = [&](int row, double v) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rp, off8, (uint32_t)row * row8, 0); };
+    auto sto = [&](int64_t row, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), ro, off4, (uint32_t)row * row4, 0); };
+    V3 pm[NDEV];
+    double sim_sum = 0.0;
+#pragma unroll
+    for (int d = 0; d < n; ++d) {
+        double pv[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            pv[k] = ldp(d * 3 + k);
+            const double tv = ldt(d * 3 + k);
+            sto(obs_row_target(a.obs_mode, n, d, k), (float)tv);
+            sim_sum += pv[k] * tv;
+        }
+        pm[d] = V3{pv[0], pv[1], pv[2]};
+    }
+    const double prev_sim = sim_sum / n;                                               // array_env.py:372-373
+    // _apply_action in 'global' mode (array_env.py:411-445): the action is [current, duration]; action[1] is what the reference reads
+    // as the current density and the duration defaults to 1 ns -- kept as is
+    double J = (double)a.actions[N + i];
+    double T = 1e-9;
+    J = isnan(J) ? J : fmin(fmax(J, -a.max_current), a.max_current);
+    T = isnan(T) ? T : fmin(fmax(T, 1e-12), a.max_duration);
+    const bool drive = fabs(J) > 1e-12;                                                // array_env.py:506
+    double e_total = 0.0;
+    if (drive) {
+#pragma unroll 1
+        for (int d = 0; d < n; ++d) {
+            const V3 m0 = pm[0];
+            V3 h = device_field(m0, a.dev);
+            if (a.include_coupling) {                                                  // array_env.py:485-492
+                const double* crow = lc + d * n;                                       // crow[k] = C[d][(d + k) mod n]
+                V3 hc{0.0, 0.0, 0.0};
+#pragma unroll
+                for (int k = 1; k < n; ++k) {
+                    const double c = crow[k];
+                    hc = V3{hc.x + c * pm[k].x, hc.y + c * pm[k].y, hc.z + c * pm[k].z};
+                }
+                h = V3{h.x + hc.x, h.y + hc.y, h.z + hc.z};
+            }
+            // _simulate_device_dynamics (array_env.py:496-521): alpha = 0.01, gamma = 2.21e5, p_hat = z
+            const V3 mxp{m0.y, -m0.x, 0.0};
+            const V3 t2 = cross(m0, mxp);
+            const double tj = 0.1 * J;
+            const V3 mxh = cross(m0, h);
+            V3 dm{-2.21e5 * mxh.x, -2.21e5 * mxh.y, -2.21e5 * mxh.z};
+            const V3 mxdm = cross(m0, dm);
+            dm = V3{dm.x + 0.01 * mxdm.x + tj * t2.x, dm.y + 0.01 * mxdm.y + tj * t2.y, dm.z + 0.01 * mxdm.z + tj * t2.z};
+            const double dt = T / 10;
+            V3 m = m0;
+#pragma unroll
+            for (int it = 0; it < 10; ++it) {
+                m = V3{m.x + dm.x * dt, m.y + dm.y * dt, m.z + dm.z * dt};
+                const double inv = rsqrt_fast(dot(m, m));       // m / |m| (array_env.py:518), <= 2 ulp per component
+                m = V3{m.x * inv, m.y * inv, m.z * inv};
+            }
+            stp(d * 3, m.x);
+            stp(d * 3 + 1, m.y);
+            stp(d * 3 + 2, m.z);
+            // similarity: only this cell's dot product changed
+            const V3 tg{ldt(d * 3), ldt(d * 3 + 1), ldt(d * 3 + 2)};
+            sim_sum += dot(m, tg) - dot(m0, tg);
+            // energy with the resistance of the UPDATED state (current_m is a view of the pattern, array_env.py:455-463)
+            const V3 ref{a.dev.refx, a.dev.refy, a.dev.refz};
+            const double r = resistance(m, a.dev.dev_type, a.dev.r_p, a.dev.r_ap, a.dev.tmr, ref, a.dev.r_series);
+            const double v = J * r * a.dev.area;
+            e_total += (v * v) / r * T;
+            // rotate: cell d (updated) goes to the end, cell d+1 to the front
+#pragma unroll
+            for (int k = 0; k + 1 < n; ++k) pm[k] = pm[k + 1];
+            pm[n - 1] = m;
+        }
+    }
+    const double etot = a.etot[i] + e_total;
+    const int32_t step = a.step[i] + 1;
+    a.etot[i] = etot;
+    a.step[i] = step;
+    const double sim = sim_sum / n;
+    const bool is_success = sim >= a.thr;
+    // pattern rows of the observation + uniformity (1 - population std of the cell magnitudes, array_env.py:216-224)
+    double mean = 0.0;
+#pragma unroll
+    for (int d = 0; d < n; ++d) {
+        const V3 m = pm[d];
+        sto(obs_row_pattern(a.obs_mode, n, d, 0), (float)m.x);
+        sto(obs_row_pattern(a.obs_mode, n, d, 1), (float)m.y);
+        sto(obs_row_pattern(a.obs_mode, n, d, 2), (float)m.z);
+        mean += sqrt(dot(m, m));
+    }
+    mean /= n;
+    double var = 0.0;
+#pragma unroll
+    for (int d = 0; d < n; ++d) {
+        const double dv = sqrt(dot(pm[d], pm[d])) - mean;
+        var += dv * dv;
+    }
+    if (a.obs_mode == 1) {
+        sto(6 * n + 0, (float)sim);
+        sto(6 * n + 1, (float)((double)(a.max_steps - step) / (double)a.max_steps));
+        sto(6 * n + 2, (float)(etot / 1e-12));
+        sto(6 * n + 3, (float)(a.temperature / 300.0));
+    }
+    const double uniformity = fmax(0.0, 1.0 - sqrt(var / n));
+    // default reward (array_env.py:183-224): pattern match, energy (sign as written), progress, uniformity
+    double reward = 10.0 * (is_success ? 10.0 : sim * 5.0);
+    reward += (-a.w_energy) * (-e_total / 1e-12);
+    reward += (sim - prev_sim);
+    reward += 2.0 * uniformity;
+    a.reward[i] = (float)reward;
+    if (a.reward64) a.reward64[i] = reward;
+    if (a.energy) a.energy[i] = e_total;
+    a.term[i] = is_success ? 1 : 0;
+    a.trunc[i] = step >= a.max_steps ? 1 : 0;
+}
+
 // 'individual' action mode (one addressed cell per step): nothing but that one cell changes, so the step is ONE streaming
 // pass over the array -- pattern and target in, both halves of the observation out, similarity, norm statistics and the
 // addressed cell's coupling sum accumulated on the way -- with no per-lane copy of the pattern in LDS.  Only the coupling
@@ -421,7 +571,8 @@ struct stg_array_ctx {
     int32_t* step;
     uint32_t* resets;
     bool have_state = false, have_target = false;
-    int variant = 1;          // experiment knob STG_ARRAY_VARIANT: 0 generic kernel for every size, 1 (default) unrolled 4 x 4
+    int variant = 1;          // experiment knob STG_ARRAY_VARIANT: 0 generic kernel for every size, 1 (default) the 4 x 4 specialisations,
+                              // 2 the 4 x 4 kernel with the pattern in LDS in 'global' mode too
 };
 
 extern "C" {
@@ -520,6 +671,13 @@ int stg_array_step(stg_array_ctx* ctx, const float* actions, float* obs, float* 
         const size_t lds_c = c.include_coupling ? sizeof(double) * (size_t)n * n : 0;
         hipLaunchKernelGGL(stg_array_step_individual_kernel, dim3((unsigned)((ctx->N + 255) / 256)), dim3(256), lds_c,
                            (hipStream_t)stream, a);
+        AHIP_TRY(hipGetLastError());
+        return STG_OK;
+    }
+    if (c.action_mode == 3 && n == 16 && ctx->variant >= 1 && ctx->variant != 2 && ctx->N <= (4ll << 20)) {
+        // 'global' mode on 4 x 4 arrays: fully unrolled sweep, pattern in registers (STG_ARRAY_VARIANT=2: the LDS form of this size)
+        const size_t lds_c = c.include_coupling ? sizeof(double) * (size_t)n * n : 0;
+        hipLaunchKernelGGL((stg_array_step_global_kernel<16>), dim3((unsigned)((ctx->N + 255) / 256)), dim3(256), lds_c, (hipStream_t)stream, a);
         AHIP_TRY(hipGetLastError());
         return STG_OK;
     }

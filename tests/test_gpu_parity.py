@@ -883,6 +883,52 @@ def test_array_vec_env_vs_oracle(stg, mode):
     assert hip[3][3].all() and hip[1][2].any()          # truncation at max_steps, some early successes
 
 
+@pytest.mark.parametrize("device_type", ["stt_mram", "sot_mram"])
+def test_array_global_mode_register_kernel_vs_lds_kernels_and_oracle(stg, device_type, monkeypatch):
+    """4 x 4 arrays in 'global' mode run the kernel that keeps the pattern in (rotating) registers; STG_ARRAY_VARIANT=2 / 0 select the
+    kernels that keep it in LDS (the 4 x 4 specialisation / the general one).  Same results to the rounding of the coupling sum's order
+    (<= 1e-13 on the pattern after four steps), on a ragged batch, with and without coupling, in both observation modes, for a device
+    type with shape demagnetisation too; and the oracle within the usual 1e-11."""
+    from helpers import OracleArrayBackend
+    n = 1000
+    rng = np.random.default_rng(31)
+    v = rng.normal(0, 1, (n, 4, 4, 3))
+    init = v / np.linalg.norm(v, axis=-1, keepdims=True)
+    acts = [np.stack([rng.uniform(-2e6, 2e6, n), rng.uniform(1e-13, 1e-10, n)], axis=1).astype(np.float32) for _ in range(4)]
+    acts[1][::7, 1] = 0.0                                  # (action[1] is what 'global' mode reads as the current: some undriven arrays)
+    for coupling in (True, False):
+        for obs_mode in ("array", "vector"):
+            runs = {}
+            for name, variant, backend in (("registers", None, None), ("lds4x4", "2", None), ("general", "0", None), ("oracle", None, OracleArrayBackend)):
+                if variant is None:
+                    monkeypatch.delenv("STG_ARRAY_VARIANT", raising=False)
+                else:
+                    monkeypatch.setenv("STG_ARRAY_VARIANT", variant)
+                env = stg.SpinTorqueArrayVecEnv(n, (4, 4), device_type=device_type, action_mode="global", include_coupling=coupling,
+                                                coupling_type="dipolar", coupling_strength=0.2, observation_mode=obs_mode,
+                                                success_threshold=0.05, max_steps=3, backend=backend)
+                obs, _ = env.reset(options={"initial_pattern": init})
+                rec = []
+                for a in acts:
+                    obs, r, te, tr, info = env.step(torch.from_numpy(a))
+                    rec.append((obs.cpu().numpy().copy(), info["reward_f64"].cpu().numpy().copy(), te.cpu().numpy().copy(),
+                                tr.cpu().numpy().copy(), info["energy"].cpu().numpy().copy(), env.get_state()["pattern"].cpu().numpy().copy()))
+                runs[name] = rec
+                env.close()
+            monkeypatch.delenv("STG_ARRAY_VARIANT", raising=False)
+            assert np.array_equal(runs["lds4x4"][-1][5], runs["general"][-1][5])            # (the two LDS kernels: same arithmetic)
+            for s in range(4):
+                reg = runs["registers"][s]
+                for other, tol in (("lds4x4", 1e-13), ("oracle", 1e-11)):
+                    o = runs[other][s]
+                    assert np.abs(reg[5] - o[5]).max() <= tol, (coupling, obs_mode, other, s, np.abs(reg[5] - o[5]).max())
+                    assert np.allclose(reg[0], o[0], rtol=3e-7, atol=1e-10) and np.allclose(reg[1], o[1], rtol=1e-9, atol=1e-9)
+                    assert np.array_equal(reg[2], o[2]) and np.array_equal(reg[3], o[3])
+                    assert np.allclose(reg[4], o[4], rtol=1e-10, atol=0)
+            if not coupling:       # no coupling sum: nothing is reordered
+                assert np.array_equal(runs["registers"][-1][5], runs["lds4x4"][-1][5])
+
+
 def test_array_env_sizes_and_device_reset(stg):
     """8 x 8 cells (LDS: 98 KB pattern + 32 KB coupling per wavefront), device-side random reset, ragged batch."""
     n = 1000

@@ -10,7 +10,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 bench.cap_host_threads()
 for rep in range(2):
     for mode in ("global", "row", "column"):
-        for v in (0, 1):
+        for v in ((0, 2, 1) if mode == "global" else (0, 1)):   # (2: the 4 x 4 LDS kernel in global mode; 1 there: pattern in registers)
             os.environ["STG_ARRAY_VARIANT"] = str(v)
             r = bench.run_array_config(n, mode, 8, 0)
             print(f"rep {rep} {mode:7s} variant {v}: kernel {r['kernel_ms_avg']:.4f} ms  ({n / (r['wall_s'] / 8):.3e} array-steps/s)", flush=True)
