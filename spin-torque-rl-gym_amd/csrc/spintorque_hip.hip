@@ -321,7 +321,10 @@ static inline void refill_auto(int64_t n, int& r, int64_t& nw) {
     nw = 1024;
     int64_t rr = (nblk + nw - 1) / nw;
     if (rr > 8) { nw = 2048; rr = (nblk + nw - 1) / nw; }
-    r = (int)(rr > 1024 ? 1024 : rr);
+    // (beyond 2048 x 1024 x 64 = 134 M envs -- they still fit the 288 GB part -- the queues get no longer, there are more of them: the
+    // contract of StepArgs is refill * refill_nw >= blocks, or envs would be left unstepped)
+    if (rr > 1024) { nw = (nblk + 1023) / 1024; rr = (nblk + nw - 1) / nw; }
+    r = (int)rr;
 }
 constexpr int32_t STG_WALK_TILES_DEFAULT = 1 << 20;   // all tiles of the group (fastest, see stg_slot_block)
 
@@ -662,6 +665,8 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
         if (ctx->refill >= 0) { r = ctx->refill; chk = ctx->refill_check; nw = r >= 2 ? (nblk + r - 1) / r : 0; }
         // (not combined with the wave-specialised launch: a forced wave_spec = 1 keeps the one-env-per-lane kernel)
         if (r >= 2 && !(ctx->cfg.thermal && ctx->cfg.wave_spec > 0)) {
+            if ((int64_t)r * nw < nblk || nw > 0x7FFFFFFFll)
+                return fail(STG_E_INVALID, "lane refill: envs per lane x queues does not cover the batch");
             a.refill = r; a.refill_check = chk > 0 ? chk : STG_REFILL_CHECK_DEFAULT; a.refill_nw = (int32_t)nw;
             stg_dispatch_step_rk45_refill(a, ctx->cfg.thermal != 0, multi, ctx->axis_z_llgs, act_f64, st);
             HIP_TRY(hipGetLastError());

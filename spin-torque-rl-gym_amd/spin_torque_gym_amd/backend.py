@@ -42,11 +42,13 @@ class EnvConfig:
     out_layout: str = "soa"                   # 'soa': obs [12,N] + reward/terminated/truncated arrays; 'records': one
                                               # [N,56]-byte record array (what the multi-GPU gather moves, copy-free)
     lane_refill: Optional[int] = None         # RK45 throughput launches: envs per lane of the lane-refill kernel; None = automatic
-                                              # (>= 262144 envs), False/0 = never, n >= 2 = force (results are bit-identical)
-    diagnostics: bool = False                 # also write the step's fp64 reward, per-step energy, status bytes and -- with
-                                              # auto-reset -- terminal observations into separate arrays (the C-ABI's optional
-                                              # outputs).  Off: those pointers are NULL, a step writes the RL-facing outputs only
-                                              # (the status still rides in byte 54 of each record with out_layout='records')
+                                              # (launches of more than 131 072 envs: include/spintorque_hip.h, cfg.lane_refill),
+                                              # False/0 = never, n >= 2 = force (results are bit-identical)
+    diagnostics: bool = False                 # also write the step's fp64 reward, per-step energy and status bytes into separate
+                                              # arrays (the C-ABI's optional outputs).  Off: those pointers are NULL, a step writes the
+                                              # RL-facing outputs only (the status still rides in byte 54 of each record with
+                                              # out_layout='records').  The terminal observations of same-step auto-reset are RL-facing
+                                              # data, not a diagnostic: `final_obs` is written whenever auto-reset is on.
 
     def to_abi(self) -> "_lib.StgConfig":
         if self.solver not in _lib.SOLVERS:
@@ -238,13 +240,14 @@ class HipBackend:
         """actions: [2,N] float32 or float64 tensor (row 0 current density, row 1 duration).  One kernel launch; the
         RL-facing outputs land in `self.packed`.  autoreset (same-step): an env whose episode ends ON THIS step reports
         this step's reward / terminated / truncated, is reset on the device inside the same launch, and its `obs` row
-        already holds the new episode's first observation; the terminal observation goes to `self.final_obs`.
+        already holds the new episode's first observation; the terminal observation goes to `self.final_obs` (always, with or
+        without `diagnostics`: a learner that bootstraps at truncation needs it; rows of other envs keep their last content).
         out ('records' layout only): another uint8 [N,56] record array to write this step's outputs into instead of
         `self.packed` (callers that double-buffer, e.g. the pipelined multi-GPU gather); the returned views are of `out`."""
         a = torch.as_tensor(actions)
         f64 = a.dtype == torch.float64
         a = self._dev(a, torch.float64 if f64 else torch.float32, (2, self.n))
-        if autoreset and self.diagnostics and self.final_obs is None:
+        if autoreset and self.final_obs is None:
             if self.records_layout:           # env-major like the records: one 48-byte block per env
                 self._final_buf = torch.zeros((self.n, 12), dtype=torch.float32, device=self.device)
                 self.final_obs = self._final_buf.t()
@@ -256,7 +259,7 @@ class HipBackend:
                 raise ValueError(f"out must be a contiguous uint8 [{self.n}, {RECORD_BYTES}] tensor on {self.device}")
             diag = self.diagnostics
             _lib.check(self.lib.stg_step_many(self._ctx, 1, _ptr(a), int(f64), 1, int(bool(autoreset)), _ptr(rec),
-                                              _ptr(self._final_buf) if (autoreset and diag) else None, None, _ptr(self.reward64),
+                                              _ptr(self._final_buf) if autoreset else None, None, _ptr(self.reward64),
                                               _ptr(self.energy), None, None, _ptr(self.status) if diag else None, self._stream()))
             self._keep = (a,)
             if out is None:
@@ -266,7 +269,7 @@ class HipBackend:
         if out is not None:
             raise ValueError("out= needs out_layout='records'")
         _lib.check(self.lib.stg_step_many(self._ctx, 1, _ptr(a), int(f64), 1, int(bool(autoreset)), _ptr(self.obs),
-                                          _ptr(self.final_obs) if (autoreset and self.diagnostics) else None,
+                                          _ptr(self.final_obs) if autoreset else None,
                                           _ptr(self.reward), _ptr(self.reward64), _ptr(self.energy),
                                           _ptr(self.terminated), _ptr(self.truncated), _ptr(self.status),
                                           self._stream()))
@@ -297,7 +300,7 @@ class HipBackend:
         self.energy_many = torch.empty((ko, n), dtype=torch.float64, device=dev) if diag else None
         fbuf = None
         self.final_obs_many = None
-        if autoreset and diag:
+        if autoreset:
             if self.records_layout:
                 fbuf = torch.zeros((ko, n, 12), dtype=torch.float32, device=dev)
                 self.final_obs_many = fbuf.transpose(1, 2)

@@ -120,9 +120,11 @@ class SpinTorqueVecEnv:
     row stride 14 floats); ``out_layout='soa'`` keeps four separate arrays with a component-major [12,N] obs buffer, of which
     ``obs`` is the transposed view.  No copies either way.  Actions are accepted as [N,2] (Gym convention) or, with
     ``actions_soa=True``, as the kernel's [2,N].
-    ``diagnostics=True`` additionally fills ``info['reward_f64']`` (the reward before rounding to fp32), ``info['energy']``
-    (the reference's info['energy_consumed'], spin_torque_env.py:474-480) and, with ``autoreset``, ``info['final_obs']``;
-    by default a step writes the RL-facing outputs only (``info['status']`` is then the records' status byte).
+    With ``autoreset`` a step also returns ``info['final_obs']`` -- the terminal observation of the envs whose episode ended on
+    this step (their ``obs`` row already holds the new episode's first observation).  ``diagnostics=True`` additionally fills
+    ``info['reward_f64']`` (the reward before rounding to fp32) and ``info['energy']`` (the reference's
+    info['energy_consumed'], spin_torque_env.py:474-480); by default a step writes the RL-facing outputs only
+    (``info['status']`` is then the records' status byte).
     """
 
     def __init__(self, num_envs: int, device_type: Union[str, Sequence[str]] = "stt_mram",
@@ -241,15 +243,16 @@ class SpinTorqueVecEnv:
             obs, rew, rew64, term, trunc, status = self.backend.step(a, autoreset=self.autoreset, out=out)
         self.profiler.add("step", time.perf_counter() - t0)
         # diagnostics=False (default): the launch writes the RL-facing outputs only; `status` is then the status byte of the
-        # records (a view; absent in the SoA layout).  diagnostics=True adds the fp64 reward, the step's Joule energy and --
-        # with auto-reset -- the terminal observations (the reference's info['energy_consumed'] etc. at N = 1).
+        # records (a view; absent in the SoA layout).  diagnostics=True adds the fp64 reward and the step's Joule energy (the
+        # reference's info['energy_consumed'] etc. at N = 1).
         info = {} if status is None else {"status": status}
+        if self.autoreset:
+            # same-step auto-reset: rows of `obs` whose episode just ended already hold the new episode's first
+            # observation; their terminal observation is in info["final_obs"] (valid where terminated | truncated) --
+            # RL-facing data (bootstrapping at truncation), so it is there whatever `diagnostics` says
+            info["final_obs"] = self.backend.final_obs.t()
         if self.diagnostics:
             info.update(reward_f64=rew64, energy=self.backend.energy)
-            if self.autoreset:
-                # same-step auto-reset: rows of `obs` whose episode just ended already hold the new episode's first
-                # observation; their terminal observation is in info["final_obs"] (valid where terminated | truncated)
-                info["final_obs"] = self.backend.final_obs.t()
         return obs.t(), rew, term.bool(), trunc.bool(), info
 
     def step_many(self, actions, out_every: bool = True, actions_soa: bool = False):
@@ -261,6 +264,8 @@ class SpinTorqueVecEnv:
         obs, rew, rew64, term, trunc, status = self.backend.step_many(a, out_every=out_every, autoreset=self.autoreset)
         self.profiler.add("step_many", time.perf_counter() - t0)
         info = {} if status is None else {"status": status}
+        if self.autoreset:
+            info["final_obs"] = self.backend.final_obs_many.transpose(1, 2)     # [K or 1, N, 12]
         if self.diagnostics:
             info.update(reward_f64=rew64, energy=self.backend.energy_many)
         return obs.transpose(1, 2), rew, term.bool(), trunc.bool(), info

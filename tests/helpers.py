@@ -138,8 +138,9 @@ class OracleBackend:
             self._obs_of(i, self.obs)
         return self.obs
 
-    def _step_once(self, a, autoreset, outs):
+    def _step_once(self, a, autoreset, outs, final=None):
         obs, reward, reward64, energy, term, trunc, status = outs
+        final = self.final_obs if final is None else final
         a = np.ascontiguousarray(a.T)          # [N,2]
         f64 = a.dtype == np.float64
         targets = np.asarray(self.cfg.target_states, dtype=np.float64).reshape(-1, 3)
@@ -165,7 +166,7 @@ class OracleBackend:
             if autoreset and self.done[i]:
                 # same-step auto-reset (csrc/spintorque_hip.hip): terminal obs -> final_obs, redraw, obs of the new episode
                 s = self.states[i]
-                self.final_obs[:, i] = obs[:, i]
+                final[:, i] = obs[:, i]
                 m, t = device_reset_draw(self.cfg.seed, self.env_id0 + i, s.rng_step, targets)
                 s.m[:] = list(m)
                 s.target[:] = list(t)
@@ -199,9 +200,11 @@ class OracleBackend:
         term = torch.zeros((ko, n), dtype=torch.uint8)
         trunc = torch.zeros((ko, n), dtype=torch.uint8)
         status = torch.zeros((ko, n), dtype=torch.uint8)
+        self.final_obs_many = torch.zeros((ko, 12, n), dtype=torch.float32)
         for k in range(K):
             j = k if out_every else 0
-            self._step_once(a[k], autoreset, (obs[j], reward[j], reward64[j], self.energy_many[j], term[j], trunc[j], status[j]))
+            self._step_once(a[k], autoreset, (obs[j], reward[j], reward64[j], self.energy_many[j], term[j], trunc[j], status[j]),
+                            final=self.final_obs_many[j])
         return obs, reward, reward64, term, trunc, status
 
     def get_state(self):

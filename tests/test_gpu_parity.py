@@ -1086,9 +1086,11 @@ def test_masked_reset_keeps_reward_and_flags_of_other_envs(stg):
 
 @pytest.mark.parametrize("layout", ["records", "soa"])
 def test_diagnostics_off_is_the_same_step_with_fewer_outputs(stg, layout):
-    """by default (diagnostics=False) a step passes NULL for the C-ABI's optional outputs (fp64 reward,
-    energy, status array, final_obs) and writes the RL-facing outputs only; obs / reward / flags / state are bit-identical to
-    diagnostics=True, the status still rides in byte 54 of each record, and info carries no fp64 extras."""
+    """VERDICT r2 item 4 / ADVICE r3: by default (diagnostics=False) a step passes NULL for the C-ABI's optional DIAGNOSTIC
+    outputs (fp64 reward, energy, status array) and writes the RL-facing outputs only; obs / reward / flags / state are
+    bit-identical to diagnostics=True, the status still rides in byte 54 of each record, and info carries no fp64 extras.
+    The terminal observations of same-step auto-reset are RL-facing: info['final_obs'] is there with diagnostics off too and
+    holds the same bits on every env whose episode ended (a learner bootstrapping at truncation reads it)."""
     n = 5000
     rng = np.random.default_rng(5)
     acts = [_uniform_actions(2e6, 1e-10, 3e-10)(rng, n, k) for k in range(3)]
@@ -1105,12 +1107,21 @@ def test_diagnostics_off_is_the_same_step_with_fewer_outputs(stg, layout):
             if diag:
                 assert {"status", "reward_f64", "energy", "final_obs"} <= set(info)
             else:
-                assert set(info) == ({"status"} if layout == "records" else set())
-                assert env.backend.reward64 is None and env.backend.energy is None and env.backend.final_obs is None
-            out.append((o.clone(), r.clone(), te.clone(), tr.clone(), info["status"].clone() if "status" in info else None))
+                assert set(info) == ({"status", "final_obs"} if layout == "records" else {"final_obs"})
+                assert env.backend.reward64 is None and env.backend.energy is None
+            ended = te | tr
+            fo = info["final_obs"]
+            assert tuple(fo.shape) == (n, 12)
+            out.append((o.clone(), r.clone(), te.clone(), tr.clone(), info["status"].clone() if "status" in info else None,
+                        fo[ended].clone(), ended.clone()))
+        # (max_steps = 2: every env is truncated on the second step -- the terminal observation differs from the new episode's first)
+        assert bool(out[1][6].all()) and not torch.equal(out[1][5], out[1][0])
+        assert bool((out[1][5][:, 8] == 0.0).all()) and bool((out[1][0][:, 8] == 1.0).all())      # steps remaining: 0 vs all
         om, rm, tem, trm, im = env.step_many(torch.from_numpy(np.stack(acts)))
-        assert ("reward_f64" in im) is diag
-        out.append((om.clone(), rm.clone(), tem.clone(), trm.clone(), im["status"].clone() if "status" in im else None))
+        assert ("reward_f64" in im) is diag and tuple(im["final_obs"].shape) == (3, n, 12)
+        endm = tem | trm
+        out.append((om.clone(), rm.clone(), tem.clone(), trm.clone(), im["status"].clone() if "status" in im else None,
+                    im["final_obs"][endm].clone(), endm.clone()))
         out.append(env.get_state()["m"].clone())
         res.append(out)
         env.close()
@@ -1119,6 +1130,7 @@ def test_diagnostics_off_is_the_same_step_with_fewer_outputs(stg, layout):
             assert torch.equal(x, y), (layout, k)
         if layout == "records":
             assert torch.equal(res[0][k][4], res[1][k][4])
+        assert torch.equal(res[0][k][5], res[1][k][5]) and torch.equal(res[0][k][6], res[1][k][6]), (layout, k, "final_obs")
     assert torch.equal(res[0][-1], res[1][-1])
 
 

@@ -410,6 +410,34 @@ def test_vector_env_spaces(stg):
     assert tuple(obs.shape) == (5, 12) and tuple(r.shape) == (5,) and te.dtype == torch.bool
 
 
+def test_autoreset_returns_terminal_observation_without_diagnostics(stg):
+    """the product default is diagnostics=False; with autoreset=True a finished env's obs row is the NEW
+    episode's first observation, so the terminal one must still come back (info['final_obs']) -- a learner that bootstraps at
+    truncation needs it.  Host logic over the oracle seam; the HIP path is checked by
+    tests/test_gpu_parity.py::test_diagnostics_off_is_the_same_step_with_fewer_outputs."""
+    n = 6
+    kw = dict(device_params=stt_default_params(volume=8.75e-11), include_thermal_fluctuations=False, seed=3, autoreset=True,
+              max_steps=2, backend=OracleBackend)
+    a = torch.tensor([[1e5, 2e-10]] * n, dtype=torch.float32)
+    res = {}
+    for diag in (False, True):
+        env = stg.SpinTorqueVecEnv(n, diagnostics=diag, **kw)
+        env.reset(seed=1)
+        _, _, _, tr1, info1 = env.step(a)
+        assert "final_obs" in info1 and not bool(tr1.any())
+        obs, _, te, tr, info = env.step(a)                       # max_steps = 2: truncated now, reset in the same step
+        assert bool(tr.all()) and ("reward_f64" in info) is diag
+        fo = info["final_obs"]
+        assert tuple(fo.shape) == (n, 12)
+        assert bool((fo[:, 8] == 0.0).all()) and bool((obs[:, 8] == 1.0).all())    # steps remaining: terminal 0, new episode all
+        assert bool((fo[:, 10] != 0).all()) and bool((obs[:, 10] == 0).all())      # last action: the pulse vs zeros after reset
+        res[diag] = (fo.clone(), obs.clone())
+        om, _, _, trm, im = env.step_many(a.unsqueeze(0).repeat(2, 1, 1))
+        assert tuple(im["final_obs"].shape) == (2, n, 12) and bool(trm.any()) and bool((im["final_obs"][trm][:, 8] == 0).all())
+        env.close()
+    assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+
+
 _GYM_DROP_IN = r"""
 import os, sys
 root = sys.argv[1]
