@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/s of the SpinTorque-v0 step path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: starts its own N ranks, one per GPU -- launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W                (the same ranks under an external launcher)
 
 A "step" is one env.step() of every environment of the batch: one launch of the fused step kernel per GPU (action
 clamp -> LLGS integration over the pulse -> energy -> observation -> reward -> termination), and for N > 1 the single
@@ -20,15 +20,17 @@ T = 0 K; the env's own RK4 solver; one cfg5 shard; cfg4: 262 144 mixed STT/SOT/V
 device-physics torque terms, and with one parameter record per env; cfg2a; the array env).  Every configuration timed
 here is compared with the oracle at the same size in tests/test_gpu_fullsize.py.
 
-What is timed.  `value` / `ms_per_step`: host wall time of ONE block of exactly --steps calls of the C-ABI step
-(HipBackend.step -> stg_step_many) between synchronizes (+ barriers for N > 1), max over ranks.  `api_ms_per_step`: the
+What is timed.  `value` / `ms_per_step`: host wall time of a block of exactly --steps calls of the C-ABI step
+(HipBackend.step -> stg_step_many) between synchronizes (+ barriers for N > 1), max over ranks; --blocks (3) such blocks
+are timed and the MEDIAN one is reported -- where the dispatcher places the wavefronts differs from launch to launch by a
+few per cent, one block cannot tell a regression from placement luck.  `api_ms_per_step`: the
 same steps through the public SpinTorqueVecEnv.step() with Gym-convention [N, 2] actions (headline and cfg2).
 Timing hygiene (profiles/r03_stall_root_cause.txt): the GPU boxes show 256 CPUs but the container's CFS quota is 16; torch's
 default pool of 128 host threads made the container get THROTTLED for up to 100 ms right after a row's set-up -- the
 "sporadic ~80 ms stall" of rounds 1-2.  The pool is capped (cap_host_threads), the collector is off inside a block, events
-exist before the block, and a block is timed again (at most twice) ONLY if cgroup cpu.stat reports a throttling event during
-it -- never on the measured times.  Every block's wall time is printed: `block_walls_ms`, `block_throttled`, `blocks_timed`
-are the LAST keys of the line.
+exist before the block, and a block is discarded and replaced (at most twice) ONLY if cgroup cpu.stat reports a throttling
+event during it -- never on the measured times.  Every block's wall time is printed: `block_walls_ms`, `block_throttled`,
+`block_used`, `blocks_timed` are the LAST keys of the line.
 
 Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 
@@ -41,12 +43,15 @@ per RK45 attempt -- more than the kernels execute, because they fold constants) 
 The counters are collected LIVE: at N = 1 this script first runs itself three times under `rocprofv3 --kernel-trace
 --pmc ...` (one pass per counter group: FETCH_SIZE and WRITE_SIZE cannot share one) on the same seeded workloads,
 BEFORE this process touches the GPU, and maps the dispatches to the rows through marker launches.  If rocprofv3 is not
-usable, the committed table profiles/r03_pmc_rows.json is used when it was measured on this very library build (sha256
+usable, the committed table profiles/r04_pmc_rows.json is used when it was measured on this very library build (sha256
 of the .so), and `frac`/`traffic` are null otherwise: no stale number is ever printed.
 
-N > 1: check_ranks() asserts that the process group spans --gpus ranks on as many distinct GPUs (RCCL); besides the
-pipelined loop the line carries `no_gather` (no exchange at all) and `gather_only` with the exchange by itself for all
-three forms (all_gather, in-place all_gather, one-shot p2p) in one run.
+N > 1: rank 0 runs the counter passes for the headline row (a rank's step kernel is the single-GPU kernel of its shard) before
+it joins the process group, and the CPU baseline after the timed region while the other ranks wait -- the line carries
+`roofline` and `cpu_baseline` like the N = 1 line.  check_ranks() asserts that the process group spans --gpus ranks on as many
+distinct GPUs (RCCL); besides the pipelined loop the line carries `no_gather` (no exchange at all) and `gather_only` with the
+exchange by itself for all three forms (all_gather, in-place all_gather, one-shot p2p) in one run; if that sweep hangs, the
+measured line is still printed (with `error`) and every rank exits with code 3.
 """
 import argparse
 import csv
@@ -84,7 +89,9 @@ PMC_PASSES = {
     "fetch": "FETCH_SIZE",
     "write": "WRITE_SIZE",
 }
-PMC_TABLE = os.path.join(ROOT, "profiles", "r03_pmc_rows.json")
+PMC_TABLE = os.path.join(ROOT, "profiles", "r04_pmc_rows.json")
+LAUNCH_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
+              "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS")
 # (prefixes: every env-step / array-step kernel of the library, whatever its variant is called -- a kernel missing from an explicit
 # list silently cost the whole counter table twice)
 MAIN_KERNELS = ("stg_step_", "stg_array_step_")
@@ -116,6 +123,9 @@ def parse_args():
                     help="auto: collect the hardware counters live with rocprofv3 child passes (N = 1 only)")
     ap.add_argument("--pmc-dump", default=None, help="write the per-row counter table (JSON) here as well")
     ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)     # internal: run the rows once, write a manifest
+    ap.add_argument("--blocks", type=int, default=3, help="timed blocks of --steps steps per row; the MEDIAN block is reported")
+    ap.add_argument("--master-port", type=int, default=0, help="--gpus N > 1 without a launcher: rendezvous port of the ranks this "
+                    "command starts itself (0 = pick a free one)")
     return ap.parse_args()
 
 
@@ -218,32 +228,49 @@ class BlockTimer:
                 "throttled": cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0),
                 "throttled_usec": cg1.get("throttled_usec", 0) - cg0.get("throttled_usec", 0)}
 
-    def timed(self, body, tail=None, retime=True, tag="", pre=None):
-        """-> (last block, all blocks).  A block during which the container was throttled is followed by another (twice at
-        most).  `pre` runs before every block, outside the timed region (e.g. resetting the on-device work counters)."""
+    def timed(self, body, tail=None, retime=True, tag="", pre=None, post=None, nblocks=None):
+        """-> (the MEDIAN block, all blocks).  `nblocks` blocks (default --blocks = 3) of exactly `steps` steps each are timed;
+        a block during which the container was throttled is DISCARDED and replaced (twice at most; if every block was throttled
+        all are kept) -- the throttle counter decides what is discarded, the measured times never decide what is selected: the
+        reported block is the median of the kept ones by wall time (max over ranks).  `pre` runs before every block and `post(b)`
+        after it, both outside the timed region (resetting / reading the on-device work counters).  retime=False: one block."""
         import torch.distributed as dist
+        want = 1 if not retime else max(1, int(nblocks if nblocks is not None else DEFAULT_BLOCKS))
         blocks = []
         while True:
             if pre is not None:
                 pre()
             b = self.block(body, tail)
-            thr = float(b["throttled"] > 0)
+            v = [float(b["throttled"] > 0), b["wall_s"]]
             if self.world > 1:
-                flag = torch.tensor([thr], dtype=torch.float64, device=self.dev)
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-                thr = float(flag.item())
+                t = torch.tensor(v, dtype=torch.float64, device=self.dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                v = t.tolist()
+            b["discard"], b["wall_max_s"] = bool(v[0]), float(v[1])
+            if post is not None:
+                post(b)
             blocks.append(b)
             if os.environ.get("STG_BENCH_DEBUG"):
                 print("debug %s: block %d wall %.3f ms, device span %.3f ms, sum of kernel times %.3f ms, throttled %d (%d us)" % (
                     tag, len(blocks), b["wall_s"] * 1e3, b["device_span_s"] * 1e3, sum(b["kernel_ms"]), b["throttled"], b["throttled_usec"]),
                     file=sys.stderr, flush=True)
-            if not thr or len(blocks) >= 3 or not retime:
-                return b, blocks
+            clean = [x for x in blocks if not x["discard"]]
+            if len(clean) >= want or len(blocks) >= want + 2:
+                break
+        kept = clean if clean else blocks
+        med = sorted(kept, key=lambda x: x["wall_max_s"])[(len(kept) - 1) // 2]
+        for x in blocks:
+            x["used"] = x is med
+        return med, blocks
+
+
+DEFAULT_BLOCKS = 3
 
 
 def block_report(blocks):
-    return {"blocks_timed": len(blocks), "block_walls_ms": [round(b["wall_s"] * 1e3, 4) for b in blocks],
-            "block_throttled": [int(b["throttled"]) for b in blocks]}
+    """every block's wall time (max over ranks), which were discarded as throttled, which one (the median of the rest) is reported"""
+    return {"blocks_timed": len(blocks), "block_walls_ms": [round(b["wall_max_s"] * 1e3, 4) for b in blocks],
+            "block_throttled": [int(b["throttled"]) for b in blocks], "block_used": [i for i, b in enumerate(blocks) if b["used"]][0]}
 
 
 def cgroup_cpu_stat():
@@ -357,15 +384,19 @@ def run_config(n_local, solver, thermal, steps, warmup, rank, world, device_inde
     torch.cuda.synchronize(dev)
     timer = BlockTimer(dev, steps, world)
     tag = "n=%d %s th=%s tm=%s%s" % (n_local, solver, thermal, torque_model, " per-env" if per_env else "")
-    last, blocks = timer.timed(lambda k: one_step(warmup + k), drain, retime, tag, pre=lambda: backend.counters(reset=True))
-    c = backend.counters()                                           # work units of the last (= reported) block
-    out = dict(wall_s=last["wall_s"], device_span_s=last["device_span_s"], kernel_ms_avg=float(np.mean(last["kernel_ms"])),
+    def keep_counters(b):
+        b["counters"] = backend.counters()                           # work units of THIS block (reset before it)
+
+    last, blocks = timer.timed(lambda k: one_step(warmup + k), drain, retime, tag, pre=lambda: backend.counters(reset=True),
+                               post=keep_counters)
+    c = last["counters"]                                             # ... of the reported (median) block
+    out = dict(wall_s=last["wall_max_s"], device_span_s=last["device_span_s"], kernel_ms_avg=float(np.mean(last["kernel_ms"])),
                kernel_ms_min=float(np.min(last["kernel_ms"])), env_steps=c["env_steps"], work_units=c["work_units"],
                noop_steps=c["noop_steps"], launches=steps, warmup=warmup, **block_report(blocks))
     out.update(gather_only_ms=None, wall_no_gather_s=None, api_ms_per_step=None)
     if world > 1 and extras:
         # SURVEY 8e "report both": a learner that is data-parallel over the same ranks needs no gather at all
-        out["wall_no_gather_s"] = timer.timed(lambda k: one_step(warmup + k, gather=False), None, retime, tag + " no-gather")[0]["wall_s"]
+        out["wall_no_gather_s"] = timer.timed(lambda k: one_step(warmup + k, gather=False), None, retime, tag + " no-gather")[0]["wall_max_s"]
     if world > 1:
         out["gather_only_ms"] = gather_only(env, acts[warmup], steps, dev)
     if api and world == 1:
@@ -374,7 +405,7 @@ def run_config(n_local, solver, thermal, steps, warmup, rank, world, device_inde
         acts_gym = acts[warmup:].transpose(1, 2).contiguous()
         env.step(acts_gym[0])
         torch.cuda.synchronize(dev)
-        out["api_ms_per_step"] = timer.timed(lambda k: env.step(acts_gym[k]), None, retime, tag + " api")[0]["wall_s"] / steps * 1e3
+        out["api_ms_per_step"] = timer.timed(lambda k: env.step(acts_gym[k]), None, retime, tag + " api")[0]["wall_max_s"] / steps * 1e3
     env.close()
     return out
 
@@ -447,7 +478,7 @@ def run_array_config(n, mode, steps, device_index, size=(4, 4), retime=True):
     affected = {"individual": 1, "row": size[1], "column": size[0], "global": ndev}[mode]
     # algorithmic bytes per array-step: pattern + target + state + action read; addressed cells, obs, reward, flags, state written
     b = (ndev * 24 * 2 + 12 + 4 * a_dim) + (affected * 24 + ndev * 24 + 4 + 2 + 12 + 16)
-    return dict(kind="array", wall_s=last["wall_s"], kernel_ms_avg=float(np.mean(last["kernel_ms"])), launches=steps, warmup=2, n=n, bytes_per_unit=b,
+    return dict(kind="array", wall_s=last["wall_max_s"], kernel_ms_avg=float(np.mean(last["kernel_ms"])), launches=steps, warmup=2, n=n, bytes_per_unit=b,
                 **block_report(blocks),
                 workload=f"SpinTorqueArray-v0: {n} arrays of {size[0]}x{size[1]} STT cells, action_mode={mode}, dipolar coupling",
                 kernel="stg_array_step_individual_kernel" if mode == "individual" else "stg_array_step_kernel")
@@ -467,11 +498,14 @@ def run_short_pulse_config(n, steps, device_index, K=1, retime=True):
     for _ in range(2):
         call(0)
     torch.cuda.synchronize(b.device)
-    last, blocks = BlockTimer(b.device, steps).timed(call, None, retime, f"cfg2a K={K}", pre=lambda: b.counters(reset=True))
-    c = b.counters()
+    def keep_counters(blk):
+        blk["counters"] = b.counters()
+
+    last, blocks = BlockTimer(b.device, steps).timed(call, None, retime, f"cfg2a K={K}", pre=lambda: b.counters(reset=True), post=keep_counters)
+    c = last["counters"]
     env.close()
     # state read and written once per launch, actions read K times, outputs written once (out_every = False)
-    return dict(kind="short", wall_s=last["wall_s"], kernel_ms_avg=float(np.mean(last["kernel_ms"])), launches=steps, warmup=2, n=n, K=K,
+    return dict(kind="short", wall_s=last["wall_max_s"], kernel_ms_avg=float(np.mean(last["kernel_ms"])), launches=steps, warmup=2, n=n, K=K,
                 bytes_per_launch=BYTES_PER_ENV_STEP * n + 8 * n * (K - 1), env_steps=c["env_steps"], work_units=c["work_units"],
                 noop_steps=c["noop_steps"], **block_report(blocks),
                 workload=f"cfg2a: {n} STT envs, T=0K, rk45, every pulse = one 1 ps DP5 step, {K} env-step(s) per launch")
@@ -581,10 +615,10 @@ def parse_pmc_csv(outdir, manifest):
     return out
 
 
-def workload_key(args):
+def workload_key(args, world=1):
     """What the rows of a counter table depend on besides the library build."""
-    return {"envs_per_gpu": args.envs_per_gpu, "solver": args.solver, "thermal": int(bool(args.thermal)), "also": int(bool(args.also)),
-            "lane_sort": args.lane_sort, "wave_spec": args.wave_spec}
+    return {"envs_per_gpu": args.envs_per_gpu, "solver": args.solver, "thermal": int(bool(args.thermal)),
+            "also": int(bool(args.also)) if world == 1 else 0, "lane_sort": args.lane_sort, "wave_spec": args.wave_spec}
 
 
 def collect_pmc_live(argv):
@@ -599,7 +633,9 @@ def collect_pmc_live(argv):
     if not os.path.exists("/dev/kfd"):
         return None, "no GPU device node"
     work = tempfile.mkdtemp(prefix="stg_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
+    # (a rank of a multi-process run starts these passes too: the single-GPU child must not see the launcher's rendezvous variables)
+    env = {k: v for k, v in os.environ.items() if k not in LAUNCH_ENV and not k.startswith("TORCHELASTIC_")}
+    env["TMPDIR"] = "/tmp"
     merged, t0 = {}, time.time()
     try:
         for tag, ctrs in PMC_PASSES.items():
@@ -630,17 +666,17 @@ def collect_pmc_live(argv):
     return merged, f"live: 3 rocprofv3 --pmc passes of this command's workloads ({time.time() - t0:.0f} s)"
 
 
-def pmc_for_run(args, argv, live=True):
-    """-> (table or None, source string)"""
+def pmc_for_run(args, argv, world=1):
+    """-> (table or None, source string).  N > 1: rank 0 runs the passes for the headline row on its own GPU before it joins the
+    process group (the other ranks wait at the rendezvous)."""
     sha = library_sha256()
-    if not live:
-        note = "N > 1: no live passes"
-    elif args.pmc == "auto":
+    wk = workload_key(args, world)
+    if args.pmc == "auto":
         tab, note = collect_pmc_live(argv)
         if tab is not None:
             if args.pmc_dump:
                 with open(args.pmc_dump, "w") as f:
-                    json.dump({"library_sha256": sha, "steps": args.steps, "warmup": args.warmup, "workload": workload_key(args), "source": note,
+                    json.dump({"library_sha256": sha, "steps": args.steps, "warmup": args.warmup, "workload": wk, "source": note,
                                "units": "mean per timed launch; FETCH_SIZE / WRITE_SIZE in KB (uncorrected)", "rows": tab}, f, indent=1)
             return tab, note
     else:
@@ -651,9 +687,10 @@ def pmc_for_run(args, argv, live=True):
         return None, f"{note}; no committed table"
     if committed.get("library_sha256") != sha:
         return None, f"{note}; the committed table was measured on another library build"
-    if committed.get("workload") != workload_key(args):
+    cw = committed.get("workload")
+    if cw != wk and not (world > 1 and cw == dict(wk, also=cw.get("also") if isinstance(cw, dict) else 0)):
         return None, f"{note}; the committed table was measured on other workload arguments"
-    return committed["rows"], (f"{note}; committed table profiles/r03_pmc_rows.json (same library sha256, same workload arguments, "
+    return committed["rows"], (f"{note}; committed table profiles/{os.path.basename(PMC_TABLE)} (same library sha256, same workload arguments, "
                                f"measured with --steps {committed.get('steps')})")
 
 
@@ -780,9 +817,11 @@ def cpu_baseline(solver, thermal, seconds):
                       f"thermal={int(bool(thermal))}, OpenMP over envs ({t_used:.1f} s of wall time)"}
 
 
-def child_argv(args):
+def child_argv(args, world=1):
+    """arguments of the single-GPU counter passes: the same rows -- for N > 1 the headline row only (every rank's step kernel is the
+    single-GPU kernel of its shard: same envs per GPU, same records layout)"""
     return ["--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--envs-per-gpu", str(args.envs_per_gpu),
-            "--solver", args.solver, "--thermal", str(args.thermal), "--also", str(args.also), "--lane-sort", args.lane_sort,
+            "--solver", args.solver, "--thermal", str(args.thermal), "--also", str(args.also if world == 1 else 0), "--lane-sort", args.lane_sort,
             "--wave-spec", args.wave_spec, "--pmc", "off"]
 
 
@@ -808,14 +847,75 @@ def check_ranks(args, rank, local_rank, world):
             "gpus": [("%04x:%02x:%02x" % r[2:]) if r[2] >= 0 else f"cuda:{r[4]}" for r in sorted(rows)]}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: starts the N ranks as direct children of this process (RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment -- what `python -m torch.distributed.run --nproc-per-node N`
+    would set), relays rank 0's JSON line to stdout (everything else to stderr) and returns the worst exit code.  This process makes
+    no GPU call at all (`torch.cuda.device_count()` only counts devices) and never replaces itself."""
+    import socket
+    import threading
+    n = args.gpus
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and ndev < n:
+        print(f"bench.py: --gpus {n} over RCCL needs {n} GPUs, this node shows {ndev} (to rehearse the multi-rank path on fewer GPUs: "
+              f"--backend gloo)", file=sys.stderr)
+        return 2
+    port = args.master_port
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    base = {k: v for k, v in os.environ.items() if k not in LAUNCH_ENV}
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1))
+
+    def relay(r, p):
+        for line in p.stdout:
+            is_line = r == 0 and line.startswith("{") and '"metric"' in line
+            (sys.stdout if is_line else sys.stderr).write(line if is_line else f"[rank {r}] {line}")
+            (sys.stdout if is_line else sys.stderr).flush()
+
+    threads = [threading.Thread(target=relay, args=(r, p), daemon=True) for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
+    # a rank that dies leaves the others in a collective that never completes: once one has failed the rest get 60 s, then are
+    # killed (by PID: these are this process's own children)
+    failed_at = None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+            failed_at = time.time()
+        if failed_at is not None and time.time() - failed_at > 60:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    for t in threads:
+        t.join(timeout=5)
+    codes = [p.wait() for p in procs]
+    worst = max((abs(c) for c in codes), default=0)
+    if worst:
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+    return min(worst, 255)
+
+
 def main():
     args = parse_args()
+    global DEFAULT_BLOCKS
+    DEFAULT_BLOCKS = max(1, args.blocks)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process starts the N ranks itself and never touches the GPU
+        sys.exit(launch_ranks(args))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus {args.gpus}` (it launches its own "
+                         f"ranks) or under `python -m torch.distributed.run --nproc-per-node {args.gpus}`")
     host = cap_host_threads()
     if args.pmc_child:
         pmc_child(args)
@@ -834,19 +934,21 @@ def main():
         print("debug host:", host, "cgroup cpu.stat at start:", {k: v for k, v in cgroup_cpu_stat().items() if "thrott" in k or k == "nr_periods"},
               file=sys.stderr, flush=True)
     # hardware counters first: the child passes must be started before this process initialises the GPU
-    pmc_tab, pmc_src = pmc_for_run(args, child_argv(args), live=(world == 1)) if rank == 0 else (None, "rank > 0")
+    pmc_tab, pmc_src = pmc_for_run(args, child_argv(args, world), world) if rank == 0 else (None, "rank > 0")
     import torch.distributed as dist
     ranks = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         ndev = torch.cuda.device_count()
+        from datetime import timedelta
+        # (generous: ranks > 0 wait here while rank 0 runs its counter passes, up to 3 x 300 s)
         if args.backend == "nccl":
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=timedelta(minutes=30))
         else:
             local_rank = local_rank % max(ndev, 1)          # rehearsal: several ranks may share one GPU
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=timedelta(minutes=30))
         ranks = check_ranks(args, rank, local_rank, world)
     n_local = args.envs_per_gpu
     specs = row_specs(args)
@@ -872,10 +974,13 @@ def main():
                                    f"global record array, pipelined under the next kernel; the timed loop hands out the learner's typed views "
                                    f"(obs [N,12], reward, terminated, truncated) -- no copies") if world > 1 else "single GPU"},
         "host": host,
-        "timing": {"value_is": "C-ABI step (HipBackend.step -> stg_step_many) host wall time of one block of `steps` steps between synchronizes",
+        "timing": {"value_is": f"C-ABI step (HipBackend.step -> stg_step_many): host wall time of a block of exactly `steps` steps between "
+                               f"synchronizes (+ barriers, max over ranks); {DEFAULT_BLOCKS} such blocks are timed and the MEDIAN one is "
+                               f"reported (block_walls_ms lists all, block_used which)",
                    "api_ms_per_step_is": "the same steps through the public SpinTorqueVecEnv.step() with [N,2] actions",
-                   "retime_rule": "a block is timed again (at most twice) only if the container's cgroup cpu.stat shows nr_throttled "
-                                  "increasing during it (CFS bandwidth throttling of the whole container); never on the measured times",
+                   "retime_rule": "a block is DISCARDED and replaced (at most twice) only if the container's cgroup cpu.stat shows "
+                                  "nr_throttled increasing during it (CFS bandwidth throttling of the whole container); the measured "
+                                  "times never decide what is kept",
                    "gc": "Python collector disabled inside a timed block"},
         "roofline": roofline_step(meas, n_local, args.solver, False, row("headline"), pmc_src),
     }
@@ -891,20 +996,41 @@ def main():
         out["gather_only"] = {"ms": round(float(gm.item()), 4), "bytes_per_rank": 56 * n_local, "algo": args.gather_algo,
                               "note": "the exchange by itself, back to back with nothing to hide under (max over ranks); in the "
                                       "timed loop it runs on its own stream under the next step's kernel"}
+        # CPU baseline beside the N > 1 number too: rank 0 times the oracle on the host cores AFTER the timed region while the other
+        # ranks sleep on a key of the rendezvous store (no collective is pending meanwhile, nobody spins on a GPU queue)
+        out["cpu_baseline"] = None
+        if args.cpu_baseline:
+            store = None
+            try:
+                store = dist.distributed_c10d._get_default_store()
+            except Exception:       # noqa: BLE001 -- private accessor: fall back to the barrier below
+                pass
+            if rank == 0:
+                out["cpu_baseline"] = cpu_baseline(args.solver, args.thermal, args.cpu_seconds)
+                if store is not None:
+                    store.set("stg_bench_cpu_baseline_done", "1")
+            elif store is not None:
+                from datetime import timedelta
+                try:
+                    store.wait(["stg_bench_cpu_baseline_done"], timedelta(seconds=4 * args.cpu_seconds + 300))
+                except Exception:   # noqa: BLE001
+                    pass
+            dist.barrier()
         if rank == 0:
             # the in-place all-gather and the point-to-point exchange below have never run over RCCL with N > 1 (one-GPU build
             # boxes): a safety copy of the measured line goes to stderr first, in case one of them does not come back
             print("bench.py (before the exchange sweep): " + json.dumps(dict(out, **block_report_of(meas))), file=sys.stderr, flush=True)
         # ... and a watchdog on every rank: if the sweep hangs, rank 0 still prints the measured line (with the sweep marked as not
-        # finished) and every rank leaves with exit code 0 instead of sitting in a wedged collective until the launcher's timeout
+        # finished, `error` set) and every rank leaves with exit code 3 -- a wedged exchange is a failure, not a clean run
         def _sweep_timed_out():
             if rank == 0:
-                out["gather_only"]["all_algos_ms"] = {"error": f"the exchange sweep did not finish within {args.sweep_timeout:g} s and was abandoned"}
-                out["cpu_baseline"] = None
-                out.update(block_report_of(meas, order=("block_throttled", "block_walls_ms", "blocks_timed")))
+                msg = f"the exchange sweep did not finish within {args.sweep_timeout:g} s and was abandoned (exit code 3)"
+                out["gather_only"]["all_algos_ms"] = {"error": msg}
+                out["error"] = msg
+                out.update(block_report_of(meas, order=("block_throttled", "block_used", "block_walls_ms", "blocks_timed")))
                 print(json.dumps(out), flush=True)
             sys.stderr.flush()
-            os._exit(0)
+            os._exit(3)
         import threading
         dog = threading.Timer(args.sweep_timeout, _sweep_timed_out)
         dog.daemon = True
@@ -937,12 +1063,10 @@ def main():
                                                       {"bytes_per_array_step": m["bytes_per_unit"]}),
                              **block_report_of(m)})
         out["also"] = also
-    if rank == 0 and world == 1 and args.cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.solver, args.thermal, args.cpu_seconds)
-    elif rank == 0:
-        out["cpu_baseline"] = None
+    if rank == 0 and world == 1:
+        out["cpu_baseline"] = cpu_baseline(args.solver, args.thermal, args.cpu_seconds) if args.cpu_baseline else None
     # the headline's timing record goes LAST (the driver's log keeps the tail of the line)
-    out.update(block_report_of(meas, order=("block_throttled", "block_walls_ms", "blocks_timed")))
+    out.update(block_report_of(meas, order=("block_throttled", "block_used", "block_walls_ms", "blocks_timed")))
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -950,7 +1074,7 @@ def main():
         dist.destroy_process_group()
 
 
-def block_report_of(m, order=("blocks_timed", "block_walls_ms", "block_throttled")):
+def block_report_of(m, order=("blocks_timed", "block_walls_ms", "block_throttled", "block_used")):
     return {k: m[k] for k in order}
 
 

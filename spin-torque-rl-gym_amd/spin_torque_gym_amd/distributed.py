@@ -52,7 +52,8 @@ class ShardedSpinTorqueVecEnv:
     """`num_envs` global environments sharded over the ranks of `group` (default: the world group)."""
 
     def __init__(self, num_envs: int, group: Optional[dist.ProcessGroup] = None, device_index: Optional[int] = None,
-                 class_index=None, gather_algo: str = "all_gather", inplace: bool = False, **env_kwargs):
+                 class_index=None, gather_algo: str = "all_gather", inplace: bool = False, overlap: Optional[bool] = None,
+                 **env_kwargs):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised (backend 'nccl' = RCCL on ROCm, or 'gloo')")
         if gather_algo not in ("all_gather", "p2p"):
@@ -93,7 +94,11 @@ class ShardedSpinTorqueVecEnv:
         self._last = None         # ... whether gathered or not (gather_again)
         self._pending = None
         self._gloo = dist.get_backend(group) == "gloo"
-        self._overlap = dev.type == "cuda" and not self._gloo
+        # the exchange on its own HIP stream, ordered against the step kernels by events.  Automatic: RCCL (stream-ordered
+        # collectives).  Over gloo the exchange is a host-side copy out / collective / copy in and gains nothing from a side
+        # stream; overlap=True still routes it through the same stream-and-event protocol (the staging copies run on the side
+        # stream), which is how the protocol is tested with two processes on ONE GPU, where RCCL cannot run.
+        self._overlap = dev.type == "cuda" and (not self._gloo if overlap is None else bool(overlap))
         self._done = [None, None]
         if self._overlap:
             self._comm_stream = torch.cuda.Stream(device=dev)
@@ -110,6 +115,8 @@ class ShardedSpinTorqueVecEnv:
         if self._gloo:
             # CPU tests / single-GPU rehearsal: gloo moves host memory and is not an in-place collective
             host = torch.empty(g.shape, dtype=torch.uint8)
+            # (device tensors: .cpu() / copy_ run on the CURRENT stream -- the side stream when the caller is gather_begin with
+            # overlap -- and block the host until that stream has reached them)
             if self.gather_algo == "p2p" and self.world > 1:
                 src = mine.cpu()
                 ops = []

@@ -72,13 +72,45 @@ def _run_hip(stg, n, m0, tgt, acts, cls=None, keep=None, **kw):
         st = env.get_state()
         d = dict(obs=sel(o.t()).clone(), reward=sel(info["reward_f64"]).clone(), term=sel(te).clone(), trunc=sel(tr).clone(),
                  status=sel(info["status"]).clone(), energy=sel(info["energy"]).clone(), m=sel(st["m"]).clone(),
-                 step_count=sel(st["step_count"]).clone())
+                 step_count=sel(st["step_count"]).clone(), reward32=sel(r).clone(), etot=sel(st["total_energy"]).clone())
         if kw.get("autoreset"):
             d["final_obs"] = sel(info["final_obs"].t()).clone()
         rec.append(d)
     counters = env.backend.counters()
     env.close()
     return rec, counters
+
+
+DEFAULT_FORM_KEYS = ("obs", "reward32", "term", "trunc", "status", "m", "step_count", "etot", "final_obs")
+
+
+def _assert_benchmarked_form_same_bits(stg, hip_rec, counters, n, m0, tgt, acts, tag, cls=None, keep=None, **kw):
+    """VERDICT r3 item 3 / ADVICE r3: bench.py times the env's DEFAULT form -- diagnostics off: the C-ABI's optional fp64-reward /
+    energy / status-array pointers are NULL, the step writes the 56-byte records (+ terminal observations) only -- while the oracle
+    comparisons above run with diagnostics=True.  Same launch, same kernel instantiation: obs / fp32 reward / terminated /
+    truncated / the records' status byte / final_obs and the state (m, step count, accumulated energy) must be bit-identical, and the
+    on-device work counters equal.  `hip_rec`: what _run_hip returned for the same inputs."""
+    env = stg.SpinTorqueVecEnv(n, class_index=cls, **kw)
+    assert env.diagnostics is False and env.backend.reward64 is None and env.backend.energy is None
+    env.reset(options={"initial_state": m0, "target_state": tgt})
+    sel = (lambda t: t.index_select(-1, keep)) if keep is not None else (lambda t: t)
+    for k, a in enumerate(acts):
+        o, r, te, tr, info = env.step(torch.from_numpy(a))
+        assert "reward_f64" not in info and "energy" not in info
+        st = env.get_state()
+        d = dict(obs=sel(o.t()), reward32=sel(r), term=sel(te), trunc=sel(tr), status=sel(info["status"]), m=sel(st["m"]),
+                 step_count=sel(st["step_count"]), etot=sel(st["total_energy"]))
+        if kw.get("autoreset"):
+            d["final_obs"] = sel(info["final_obs"].t())
+        for key, v in d.items():
+            # (final_obs rows of envs that did not end hold whatever an earlier step left there: compared where the episode ended)
+            if key == "final_obs":
+                ended = (d["term"] | d["trunc"])
+                assert torch.equal(v[:, ended], hip_rec[k][key][:, ended]), (tag, "diagnostics off", k, key)
+            else:
+                assert torch.equal(v, hip_rec[k][key]), (tag, "diagnostics off", k, key, int((v != hip_rec[k][key]).sum()))
+    assert env.backend.counters() == counters, (tag, "diagnostics off: work counters")
+    env.close()
 
 
 def _run_oracle_slice(stg, s0, m0, tgt, acts, cls=None, **kw):
@@ -154,6 +186,7 @@ def test_cfg3_headline_rk45_thermal_65536_vs_oracle_slices(stg):
         ora = _run_oracle_slice(stg, s0, m0, tgt, acts, **kw)
         worst = max(worst, _cmp_slice(hip, ora, slice(s0, s0 + SLICE), TOL_RK45, ("cfg3", s0)))
     print("cfg3 headline (rk45, thermal, 65536): worst |dm| vs oracle on slices =", worst)
+    _assert_benchmarked_form_same_bits(stg, hip, c, n, m0, tgt, acts, "cfg3 headline", **kw)      # what bench.py times
     # scheduling options change nothing at this size: producer/consumer pairs off, identity lane schedule, both
     for opt in (dict(wave_spec=False), dict(lane_sort=False), dict(wave_spec=False, lane_sort=False)):
         other, c2 = _run_hip(stg, n, m0, tgt, acts, **kw, **opt)
@@ -198,6 +231,7 @@ def test_cfg5_shard_rk45_thermal_131072_vs_oracle_slices(stg):
         env.close()
         worst = max(worst, _cmp_slice(hip, ora, slice(s0, s0 + SLICE), TOL_RK45, ("cfg5 shard", s0)))
     print("cfg5 shard (rk45, thermal, 131072, env_id0 = 393216): worst |dm| vs oracle on slices =", worst)
+    _assert_benchmarked_form_same_bits(stg, hip, c, n, m0, tgt, acts, "cfg5 shard", env_id0=id0, **kw)
     other, c2 = _run_hip(stg, n, m0, tgt, acts, env_id0=id0, **kw, lane_sort=False)
     _assert_same_bits(hip, other, "cfg5 shard lane_sort off")
     assert c2 == c
@@ -217,6 +251,7 @@ def test_cfg3_rk4_thermal_65536_vs_oracle_slices(stg):
         ora = _run_oracle_slice(stg, s0, m0, tgt, acts, **kw)
         worst = max(worst, _cmp_slice(hip, ora, slice(s0, s0 + SLICE), 1e-9, ("cfg3-rk4", s0)))
     print("cfg3 rk4 thermal 65536: worst |dm| vs oracle on slices =", worst)
+    _assert_benchmarked_form_same_bits(stg, hip, c, n, m0, tgt, acts, "cfg3-rk4", **kw)
     other, _ = _run_hip(stg, n, m0, tgt, acts, **kw, wave_spec=False, lane_sort=False)
     _assert_same_bits(hip, other, "cfg3-rk4 options")
 
@@ -250,6 +285,7 @@ def test_cfg4_mixed_262144_vs_oracle_slices(stg, torque_model):
         ora = _run_oracle_slice(stg, s0, m0, tgt, acts, cls=cls, **kw)
         worst = max(worst, _cmp_slice(hip, ora, slice(s0, s0 + SLICE), TOL_RK4, ("cfg4", torque_model, s0)))
     print(f"cfg4 ({torque_model}, 262144 mixed): worst |dm| vs oracle on slices =", worst)
+    _assert_benchmarked_form_same_bits(stg, hip, c, n, m0, tgt, acts, ("cfg4", torque_model), cls=cls, **kw)
     other, c2 = _run_hip(stg, n, m0, tgt, acts, cls=cls, **kw, lane_sort=False)
     _assert_same_bits(hip, other, ("cfg4 lane_sort off", torque_model))
     assert c2 == c
@@ -294,6 +330,7 @@ def test_cfg4_per_env_parameters_262144_vs_oracle_slices(stg):
         ora = _run_oracle_slice(stg, s0, m0, tgt, acts, cls=full_cls, device_type=types, device_params=dicts, **okw)
         worst = max(worst, _cmp_slice(hip, ora, slice(s0, s0 + SLICE), TOL_RK4, ("cfg4 per-env", s0)))
     print("cfg4 per-env (262144 mixed, own record per env): worst |dm| vs oracle on slices =", worst)
+    _assert_benchmarked_form_same_bits(stg, hip, c, n, m0, tgt, acts, "cfg4 per-env", cls=cls, **kw)
     other, c2 = _run_hip(stg, n, m0, tgt, acts, cls=cls, **kw, lane_sort=False)
     _assert_same_bits(hip, other, "cfg4 per-env lane_sort off")
     assert c2 == c
@@ -318,6 +355,7 @@ def test_lane_refill_rk45_thermal_262144_vs_oracle_slices_and_one_env_per_lane(s
         ora = _run_oracle_slice(stg, s0, m0, tgt, acts, **kw)
         worst = max(worst, _cmp_slice(hip, ora, slice(s0, s0 + SLICE), TOL_RK45, ("refill 262144", s0)))
     print("lane refill (262144, rk45 + thermal): worst |dm| vs oracle on slices =", worst)
+    _assert_benchmarked_form_same_bits(stg, hip, c, n, m0, tgt, acts, "refill 262144", **kw)
     for variant in (dict(lane_refill=False), dict(lane_refill=2), dict(lane_refill=8), dict(lane_sort=False)):
         other, c2 = _run_hip(stg, n, m0, tgt, acts, **kw, **variant)
         _assert_same_bits(hip, other, ("refill variant", variant))
@@ -340,6 +378,7 @@ def test_lane_refill_rk45_thermal_1048576_vs_oracle_slices(stg):
         ora = _run_oracle_slice(stg, s0, m0, tgt, acts, **kw)
         worst = max(worst, _cmp_slice(hip, ora, slice(j * SLICE, (j + 1) * SLICE), TOL_RK45, ("refill 1M", s0)))
     print("lane refill (1048576, rk45 + thermal): worst |dm| vs oracle on slices =", worst)
+    _assert_benchmarked_form_same_bits(stg, hip, c, n, m0, tgt, acts, "refill 1M", keep=keep, **kw)
     other, c2 = _run_hip(stg, n, m0, tgt, acts, keep=keep, lane_refill=False, **kw)
     _assert_same_bits(hip, other, "refill 1M vs one env per lane")
     assert c2 == c
@@ -449,6 +488,7 @@ def test_cfg2_rk45_4096_every_env_vs_oracle(stg):
         ora = _run_oracle_slice(stg, s0, m0, tgt, acts, **kw)
         worst = max(worst, _cmp_slice(hip, ora, slice(s0, s0 + SLICE), TOL_RK45, ("cfg2", s0)))
     print("cfg2 rk45 4096 (every env): worst |dm| vs oracle =", worst)
+    _assert_benchmarked_form_same_bits(stg, hip, c, n, m0, tgt, acts, "cfg2", **kw)
     other, _ = _run_hip(stg, n, m0, tgt, acts, **kw, lane_sort=False)
     _assert_same_bits(hip, other, "cfg2 lane_sort off")
 
