@@ -386,11 +386,13 @@ def run_config(n_local, solver, thermal, steps, warmup, rank, world, device_inde
     tag = "n=%d %s th=%s tm=%s%s" % (n_local, solver, thermal, torque_model, " per-env" if per_env else "")
     def keep_counters(b):
         b["counters"] = backend.counters()                           # work units of THIS block (reset before it)
+        # ... and where the dispatcher put the wavefronts of each of its launches (stg_get_placement keeps the last 32 launches)
+        b["placement"] = [backend.placement(steps - 1 - k) for k in range(steps)] if steps <= 32 else None
 
     last, blocks = timer.timed(lambda k: one_step(warmup + k), drain, retime, tag, pre=lambda: backend.counters(reset=True),
                                post=keep_counters)
     c = last["counters"]                                             # ... of the reported (median) block
-    out = dict(wall_s=last["wall_max_s"], device_span_s=last["device_span_s"], kernel_ms_avg=float(np.mean(last["kernel_ms"])),
+    out = dict(wall_s=last["wall_max_s"], placement=last["placement"], kernel_ms=[round(x, 4) for x in last["kernel_ms"]], device_span_s=last["device_span_s"], kernel_ms_avg=float(np.mean(last["kernel_ms"])),
                kernel_ms_min=float(np.min(last["kernel_ms"])), env_steps=c["env_steps"], work_units=c["work_units"],
                noop_steps=c["noop_steps"], launches=steps, warmup=warmup, **block_report(blocks))
     out.update(gather_only_ms=None, wall_no_gather_s=None, api_ms_per_step=None)
@@ -735,6 +737,7 @@ def roofline_step(meas, n_local, solver, mixed, pmc_row, pmc_src, per_env=False)
             "valu_issue_frac": round(ex["valu_issue_frac"], 4) if ex and ex["valu_issue_frac"] is not None else None,
             "executed_flops_per_work_unit": round(ex["flops_per_launch"] / units_per_launch, 1) if ex else None,
             "kernel": (pmc_row or {}).get("kernel_name", "stg_step_kernel"), "kernel_ms_avg": round(meas["kernel_ms_avg"], 4),
+            "placement": placement_report(meas),
             "work_units_per_env_step": round(meas["work_units"] / max(meas["env_steps"], 1), 2),
             "noop_frac": round(meas["noop_steps"] / max(meas["env_steps"], 1), 6),
             "work_equiv": {"tflops": round(we, 3), "flops_per_work_unit": flops_per_unit,
@@ -743,6 +746,20 @@ def roofline_step(meas, n_local, solver, mixed, pmc_row, pmc_src, per_env=False)
             "hbm": {"achieved": round(gbs, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 7),
                     "bytes_per_env_step": bpe},
             "pmc_source": pmc_src}
+
+
+def placement_report(meas):
+    """What the dispatcher did with the launches of the reported block (the library records the SIMD of every wavefront of a launch:
+    stg_get_placement).  simd_double_booked[k] = SIMDs that held two or more INTEGRATING wavefronts of launch k; the schedules of the
+    launches of up to 65 536 envs (one integrating wavefront per SIMD; wave-specialised pairs) aim at 0, and a launch that got more
+    is slow by placement, not by code: kernel_ms lists the same launches' HIP-event times."""
+    pl = meas.get("placement")
+    if not pl:
+        return None
+    db = [p["simd_double_booked"] for p in pl]
+    return {"workgroups": pl[-1]["workgroups"], "waves_per_workgroup": pl[-1]["waves_per_workgroup"], "simds_used": [p["simds_used"] for p in pl],
+            "simd_double_booked": db, "simd_double_booked_mean": round(float(np.mean(db)), 2), "kernel_ms": meas.get("kernel_ms"),
+            "integrating_wavefronts_per_simd_last_launch": pl[-1]["integrating_per_simd"]}
 
 
 def roofline_hbm(meas, bytes_per_launch, pmc_row, pmc_src, extra=None):

@@ -339,6 +339,8 @@ struct stg_ctx {
     int32_t ncls = 0;
     const uint8_t* cls = nullptr;     // caller-owned device pointer
     unsigned long long* counters = nullptr;
+    uint32_t* placement = nullptr;    // [PLACEMENT_RING][PLACEMENT_WORDS]: where the wavefronts of the last launches ran (stg_get_placement)
+    uint64_t launch_seq = 0;          // step launches so far
     uint32_t* perm = nullptr;
     void* act_sorted = nullptr;       // [N][2] actions of the step in slot order (written by the plan kernel)
     bool have_params = false, have_state = false;
@@ -437,7 +439,8 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
     const size_t N = (size_t)n_envs;
     const size_t rs = al(N * sizeof(EnvRec)), r4 = al(N * 4), ra = al(N * 16);
-    const size_t total = rs + r4 + ra + al(sizeof(double) * STG_MAX_CLASSES * C_COUNT) +
+    const size_t rp = al(sizeof(uint32_t) * PLACEMENT_RING * PLACEMENT_WORDS);
+    const size_t total = rs + r4 + ra + rp + al(sizeof(double) * STG_MAX_CLASSES * C_COUNT) +
                          COUNTER_STRIPES * COUNTER_STRIDE * sizeof(unsigned long long);
     hipError_t e = hipMalloc(&c->slab, total);
     if (e != hipSuccess) { delete c; return fail(STG_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
@@ -449,6 +452,7 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     c->counters = (unsigned long long*)p; p += COUNTER_STRIPES * COUNTER_STRIDE * sizeof(unsigned long long);
     c->perm = (uint32_t*)p; p += r4;
     c->act_sorted = (void*)p; p += ra;
+    c->placement = (uint32_t*)p; p += rp;
     *out = c;
     return STG_OK;
 }
@@ -607,6 +611,8 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
     a.s = ctx->s; a.c = cfg_view(ctx->cfg); a.N = ctx->N; a.env_id0 = ctx->env_id0;
     a.ctab = ctx->ctab; a.cls = ctx->cls; a.ncls = ctx->ncls; a.ep = env_params_of(ctx);
     a.counters = ctx->counters;
+    a.placement = ctx->placement + (size_t)(ctx->launch_seq % PLACEMENT_RING) * PLACEMENT_WORDS;
+    ctx->launch_seq += 1;
     hipStream_t st = (hipStream_t)stream;
     a.perm = nullptr;
     // lane_sort: 0 = automatic (on: the single LDS-only plan kernel costs ~5 us and the sorted schedule is never slower
@@ -796,6 +802,23 @@ int stg_get_counters(stg_ctx* ctx, uint64_t* out, int32_t reset) {
     }
     if (reset) HIP_TRY(hipMemset(ctx->counters, 0, sizeof(h)));
     return STG_OK;
+}
+
+int stg_get_placement(stg_ctx* ctx, int32_t launches_back, uint32_t* out, int32_t cap, int32_t* n_workgroups, int32_t* waves_per_workgroup) {
+    if (!ctx || !out || cap < 1) return fail(STG_E_INVALID, "ctx/out is NULL or cap < 1");
+    if (launches_back < 0 || launches_back >= PLACEMENT_RING || (uint64_t)launches_back >= ctx->launch_seq)
+        return fail(STG_E_INVALID, "launches_back must address one of the last launches (at most 32 are kept)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    static thread_local uint32_t h[PLACEMENT_WORDS];
+    const uint64_t seq = ctx->launch_seq - 1 - (uint64_t)launches_back;
+    HIP_TRY(hipMemcpy(h, ctx->placement + (size_t)(seq % PLACEMENT_RING) * PLACEMENT_WORDS, sizeof(h), hipMemcpyDeviceToHost));
+    const int64_t waves = (int64_t)h[0] * (int64_t)h[1];
+    const int32_t n = (int32_t)(waves < PLACEMENT_CAP ? waves : PLACEMENT_CAP);
+    if (n_workgroups) *n_workgroups = (int32_t)h[0];
+    if (waves_per_workgroup) *waves_per_workgroup = (int32_t)h[1];
+    for (int32_t j = 0; j < n && j < cap; ++j) out[j] = h[2 + j];
+    return n < cap ? n : cap;
 }
 
 int stg_thermal_normals(stg_ctx* ctx, uint32_t env_step, uint32_t call0, int32_t n_calls, double* z, void* stream) {

@@ -79,6 +79,7 @@ struct StepArgs {
     const uint32_t* perm;         // lane -> env (duration-sorted schedule) or nullptr
     const void* act_sorted;       // with perm: the first fused step's actions in slot order, [N][2] in their own dtype
     unsigned long long* counters; // [4]: env-steps, integrator sub-steps/attempts, RHS evaluations, no-op steps
+    uint32_t* placement;          // this launch's placement table (record_placement) or nullptr
     float* obs;                   // [K or 1][12][N]
     float* final_obs;             // [K or 1][12][N] (records: [K or 1][N][12]) or nullptr: terminal observation of envs auto-reset at that step
     float* reward;                // [K or 1][N]
@@ -292,6 +293,26 @@ __device__ __forceinline__ void write_record_obs(void* base, int64_t i, const V3
     float2* rec = (float2*)((char*)base + i * STG_RECORD_BYTES);
 #pragma unroll
     for (int k = 0; k < 6; ++k) rec[k] = make_float2(o[2 * k], o[2 * k + 1]);
+}
+
+// Where the dispatcher put this launch's wavefronts (stg_get_placement).  The schedules above lean on observed dispatcher behaviour
+// (workgroup b on XCD b % 8, a CU takes workgroups q, q + 32, ..., which wavefronts share a SIMD); the release build records what a
+// launch actually got so that a slow run can be told from a slow build: one lane of every wavefront stores its HW_ID / XCC_ID once
+// per launch -- two s_getreg_b32 and one 4-byte store per wavefront, nothing in any loop.
+//   table[0] = workgroups of the launch, table[1] = wavefronts per workgroup, table[2 + b * wpw + wave] = entry (first
+//   PLACEMENT_CAP wavefronts): bits 0-15 HW_ID[15:0] (wave slot 3:0, SIMD 5:4, pipe 7:6, CU 11:8, SH 12, SE 15:13), bits 16-19
+//   XCC_ID, bit 20 producer wavefront of a wave-specialised pair, bit 31 valid.
+constexpr int PLACEMENT_CAP = 4096;
+constexpr int PLACEMENT_WORDS = 2 + PLACEMENT_CAP;
+constexpr int PLACEMENT_RING = 32;        // tables kept: one per launch, the last PLACEMENT_RING launches
+__device__ __forceinline__ void record_placement(uint32_t* table, int wave, int lane, bool producer) {
+    if (table == nullptr || lane != 0) return;
+    const uint32_t wpw = blockDim.x >> 6, idx = blockIdx.x * wpw + (uint32_t)wave;
+    if (idx == 0u) { table[0] = gridDim.x; table[1] = wpw; }
+    if (idx >= (uint32_t)PLACEMENT_CAP) return;
+    const uint32_t hw = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);      // HW_REG_HW_ID bits 15:0
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);     // HW_REG_XCC_ID bits 3:0
+    table[2 + idx] = (hw & 0xFFFFu) | ((xcc & 0xFu) << 16) | (producer ? (1u << 20) : 0u) | (1u << 31);
 }
 
 constexpr int COUNTER_STRIPES = 1024;     // copies of the on-device counters (one 64-byte line each)
@@ -596,6 +617,7 @@ stg_step_kernel(const StepArgs a) {
     if (PC && a.hybrid) hyb_slot = stg_hybrid_block(blockIdx.x, wave, (uint32_t)(a.hybrid - 1), (a.N + TILE_ENVS - 1) / TILE_ENVS, paired);
     const bool producer = PC && paired && wave >= WGW;
     const int cw = producer ? (2 * WGW - 1 - wave) : (wave < WGW ? wave : wave - WGW);   // the integrating wavefront this one is, or serves
+    record_placement(a.placement, wave, lane, producer);
     const int64_t lane_slot = ((PC && a.hybrid) ? hyb_slot
                                                 : stg_slot_block<WGW>(blockIdx.x, (uint32_t)((a.N + WGW * 64 - 1) / (WGW * 64)), a.perm != nullptr, cw, PC,
                                                                       (uint32_t)a.walk, (uint32_t)a.spread_max) * 64) + lane;
@@ -717,6 +739,7 @@ __global__ void __launch_bounds__(WGW * 64) stg_step_refill_kernel(const StepArg
     const int R = a.refill;
     const int64_t tiles = (N + TILE_ENVS - 1) / TILE_ENVS, nblk = tiles * TILE_WAVES, nw = a.refill_nw;   // (blocks of whole tiles)
     const int64_t w = (int64_t)blockIdx.x * WGW + wave;
+    record_placement(a.placement, wave, lane, false);
     if (w >= nw) return;
     const AT* act = (const AT*)a.actions;
     const Recorder norec{};

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("STG_HIP_LIBRARY") or os.path.join(_HERE, "libspintorq
 
 STG_MAX_TARGETS = 8
 STG_MAX_CLASSES = 64
-ABI_VERSION = 3          # STG_ABI_VERSION of include/spintorque_hip.h this binding was written against
+ABI_VERSION = 4          # STG_ABI_VERSION of include/spintorque_hip.h this binding was written against
 STG_NPARAM = 30          # double-valued fields of stg_device_params, in declaration order
 SOLVERS = {"rk4": 0, "euler": 1, "rk45": 2}
 DEV_TYPES = {"stt_mram": 0, "sot_mram": 1, "vcma_mram": 2}
@@ -70,6 +70,7 @@ SYMBOLS = {
     "stg_set_state": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "stg_device_terms": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "stg_get_counters": (C.c_int, [_VP, C.POINTER(C.c_uint64), C.c_int32]),
+    "stg_get_placement": (C.c_int, [_VP, C.c_int32, C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "stg_solve": (C.c_int, [_VP, _VP, _VP, _VP, C.c_uint32, _VP, _VP, _VP, _VP]),
     "stg_solve_traj": (C.c_int, [_VP, _VP, _VP, _VP, C.c_uint32, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "stg_thermal_strength": (C.c_int, [_VP, C.c_int32, C.POINTER(C.c_double)]),

@@ -384,6 +384,30 @@ class HipBackend:
         _lib.check(self.lib.stg_get_counters(self._ctx, out, int(bool(reset))))
         return {"env_steps": int(out[0]), "work_units": int(out[1]), "noop_steps": int(out[3])}
 
+    PLACEMENT_CAP = 4096
+
+    def placement(self, launches_back=0):
+        """Where the dispatcher put the wavefronts of a recent step launch (stg_get_placement; 0 = the latest, up to 31 back):
+        dict(workgroups, waves_per_workgroup, simds_used, integrating_per_simd (histogram {count: SIMDs}), simd_double_booked).
+        `simd_double_booked` = SIMDs that held two or more INTEGRATING wavefronts of the launch -- for the launches scheduled
+        for one integrating wavefront per SIMD (up to 65 536 envs; the wave-specialised pairs) it should be 0, and every such
+        SIMD costs the launch the time of its two wavefronts back to back.  Synchronises the device."""
+        out = (C.c_uint32 * self.PLACEMENT_CAP)()
+        nwg, wpw = C.c_int32(), C.c_int32()
+        n = self.lib.stg_get_placement(self._ctx, int(launches_back), out, self.PLACEMENT_CAP, C.byref(nwg), C.byref(wpw))
+        if n < 0:
+            _lib.check(n)
+        w = np.frombuffer(out, dtype=np.uint32, count=n).copy()
+        w = w[(w >> 31) == 1]
+        simd = (w & 0xFFFF) >> 4 & 3
+        where = ((w >> 16 & 0xF).astype(np.int64) << 12) | ((w >> 8 & 0xFF).astype(np.int64) << 2) | simd      # (xcc, se/sh/cu, simd)
+        integ = where[(w >> 20 & 1) == 0]
+        _, cnt = np.unique(integ, return_counts=True)
+        hist = {int(k): int(v) for k, v in zip(*np.unique(cnt, return_counts=True))}
+        return {"workgroups": int(nwg.value), "waves_per_workgroup": int(wpw.value), "waves_recorded": int(len(w)),
+                "simds_used": int(len(np.unique(where))), "integrating_per_simd": hist,
+                "simd_double_booked": int((cnt >= 2).sum())}
+
     def thermal_normals(self, env_step=0, call0=0, n_calls=1):
         z = torch.empty((n_calls, 3, self.n), dtype=torch.float64, device=self.device)
         _lib.check(self.lib.stg_thermal_normals(self._ctx, int(env_step), int(call0), int(n_calls), _ptr(z),

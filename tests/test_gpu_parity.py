@@ -1114,9 +1114,12 @@ def test_diagnostics_off_is_the_same_step_with_fewer_outputs(stg, layout):
             assert tuple(fo.shape) == (n, 12)
             out.append((o.clone(), r.clone(), te.clone(), tr.clone(), info["status"].clone() if "status" in info else None,
                         fo[ended].clone(), ended.clone()))
-        # (max_steps = 2: every env is truncated on the second step -- the terminal observation differs from the new episode's first)
-        assert bool(out[1][6].all()) and not torch.equal(out[1][5], out[1][0])
-        assert bool((out[1][5][:, 8] == 0.0).all()) and bool((out[1][0][:, 8] == 1.0).all())      # steps remaining: 0 vs all
+            # an env that ended: its obs row is the NEW episode's first observation (all steps remaining, no last action), the
+            # terminal one -- of a truncated env: no steps remaining -- is in final_obs
+            assert bool((o[ended][:, 8] == 1.0).all()) and bool((o[ended][:, 10:] == 0.0).all())
+            assert bool((fo[tr][:, 8] == 0.0).all()) and bool((fo[ended][:, 11] != 0.0).all())
+        # (max_steps = 2: on the second step every env that did not reach its target on the first is truncated)
+        assert float(out[1][6].float().mean()) > 0.8
         om, rm, tem, trm, im = env.step_many(torch.from_numpy(np.stack(acts)))
         assert ("reward_f64" in im) is diag and tuple(im["final_obs"].shape) == (3, n, 12)
         endm = tem | trm
@@ -1514,3 +1517,37 @@ def test_schedule_knobs_keep_the_slot_map_a_bijection(stg, monkeypatch, snake, w
         for x, y in zip(*outs):
             assert torch.equal(x, y), (n, snake, walk)
         assert bool((outs[0][3] == 1).all())
+
+
+def test_placement_table_of_a_step_launch(stg):
+    """ABI v4, stg_get_placement: every wavefront of a step launch records the SIMD it ran on (the schedules lean
+    on observed dispatcher behaviour; the shipped library can report what a launch actually got).  65 536 envs, RK45 + thermal = 1024
+    workgroups of one integrating + one producing wavefront; 4096 envs at T = 0 K = 64 one-wavefront workgroups; the ring keeps the
+    last 32 launches."""
+    n = 65536
+    rng = np.random.default_rng(0)
+    env = stg.SpinTorqueVecEnv(n, device_params=stt_default_params(volume=9.7e-6), include_thermal_fluctuations=True, solver="rk45", seed=2,
+                               autoreset=True)
+    env.reset(seed=1)
+    with pytest.raises(Exception, match="launches_back"):
+        env.backend.placement(0)                                    # nothing launched yet
+    for k in range(3):
+        env.step(torch.from_numpy(_uniform_actions(2e6, 1e-10, 2e-10)(rng, n, k)))
+    for back in range(3):
+        p = env.backend.placement(back)
+        assert p["workgroups"] == 1024 and p["waves_per_workgroup"] == 2 and p["waves_recorded"] == 2048
+        assert sum(k * v for k, v in p["integrating_per_simd"].items()) == 1024           # 1024 integrating + 1024 producing wavefronts
+        assert 512 <= p["simds_used"] <= 1024 and 0 <= p["simd_double_booked"] <= 512
+    with pytest.raises(Exception, match="launches_back"):
+        env.backend.placement(3)
+    print("placement of the 65 536-env wave-specialised launch:", p)
+    env.close()
+    env = stg.SpinTorqueVecEnv(4096, device_params=stt_default_params(volume=9.7e-6), include_thermal_fluctuations=False, solver="rk45", seed=2)
+    env.reset(seed=1)
+    for k in range(40):                                             # more launches than the ring holds
+        env.step(torch.from_numpy(_uniform_actions(2e6, 1e-11, 2e-11)(rng, 4096, k)))
+    p = env.backend.placement(31)
+    assert p["workgroups"] == 64 and p["waves_per_workgroup"] == 1 and p["waves_recorded"] == 64 and p["integrating_per_simd"] == {1: 64}
+    with pytest.raises(Exception, match="launches_back"):
+        env.backend.placement(32)
+    env.close()
