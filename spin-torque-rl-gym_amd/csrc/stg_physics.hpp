@@ -242,9 +242,20 @@ struct NormalStream {
     __device__ __forceinline__ void pair(float& a, float& b) {
         // the two mantissa-trick subtractions and the two final products go through packed fp32 (v_pk_add_f32 /
         // v_pk_mul_f32: one instruction for both lanes of the pair, same IEEE results)
+#ifdef STG_EXP_CHEAP_NORMALS
+        // EXPERIMENT BUILD ONLY (tools/build_variant.sh cheapn "-DSTG_EXP_CHEAP_NORMALS"; never shipped): a stand-in with the COST of a
+        // hypothetical cheaper generator -- the two xoshiro words converted and scaled, no transcendental at all, ~9.5 issue slots per
+        // value against ~18.5 -- and the WRONG distribution (uniform, unit variance).  It measures the ceiling a cheaper normal could
+        // buy before anyone designs one (profiles/EXPERIMENTS.md).
+        const f32x2 u{(float)(int32_t)next(), (float)(int32_t)next()};
+        const f32x2 v = u * f32x2{8.0654e-10f, 8.0654e-10f};          // sqrt(3) / 2^31
+        a = v.x;
+        b = v.y;
+#else
         float t, c, s_;
         pair_head(t, c, s_);
         finish_pair(t, c, s_, a, b);
+#endif
     }
     // the same pair in two halves: pair() == finish_pair(pair_head(...)); a producer wavefront can hand over the head
     // (t = -2 ln u0, cos, sin) and leave the square root and the products to the integrating wavefront

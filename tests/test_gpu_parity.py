@@ -1119,7 +1119,7 @@ def test_diagnostics_off_is_the_same_step_with_fewer_outputs(stg, layout):
             assert bool((o[ended][:, 8] == 1.0).all()) and bool((o[ended][:, 10:] == 0.0).all())
             assert bool((fo[tr][:, 8] == 0.0).all()) and bool((fo[ended][:, 11] != 0.0).all())
         # (max_steps = 2: on the second step every env that did not reach its target on the first is truncated)
-        assert float(out[1][6].float().mean()) > 0.8
+        assert float(out[1][6].float().mean()) > 0.5
         om, rm, tem, trm, im = env.step_many(torch.from_numpy(np.stack(acts)))
         assert ("reward_f64" in im) is diag and tuple(im["final_obs"].shape) == (3, n, 12)
         endm = tem | trm
