@@ -4,7 +4,8 @@
 //   state : EnvRec[N] = { f64 m[3], target[3], e_tot; u32 step | done << 31; u32 rng }        = 64 B/env, one record per env
 //   class table                : f64[n_classes][C_COUNT]  (derived constants, <= 64 classes)
 //   cls                        : u8[N] (caller-owned) when n_classes > 1
-//   per-env parameters         : f64[STG_NPARAM][N] + type/valid u8[N] (library-owned copy), alternative to the class table
+//   per-env parameters         : records f64[N][16 | 20 | 24] (library-owned, packed from the caller's rows: the fields the context's
+//                                solver / torque model read, stg_kernels.hpp: EnvParams), alternative to the class table
 // One lane per env; the step kernel's workgroups hold one integrating wavefront (launches below 65 536 envs: small
 // batches spread over as many CUs as they have wavefronts) or four (one per SIMD of a CU), plus, in the wave-specialised
 // thermal form, one producer wavefront each; the hot loops live entirely in registers.  With one device class the
@@ -62,7 +63,7 @@ __global__ void __launch_bounds__(64) stg_reset_kernel(const ResetArgs a) {
     __shared__ double s_tab[STG_MAX_CLASSES * C_COUNT];
     const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool in_range = i < a.N;
-    const double* row = (a.ncls > 1 || a.ep.soa) ? class_row<true>(a.ctab, a.cls, a.ncls, i, in_range, s_tab, a.ep, a.N) : a.ctab;
+    const double* row = (a.ncls > 1 || a.ep.soa) ? class_row<true>(a.ctab, a.cls, a.ncls, i, in_range, s_tab, a.ep, a.N, a.ep.layout) : a.ctab;
     if (!in_range) return;
     const int64_t N = a.N;
     V3 m0, t0;
@@ -347,7 +348,8 @@ struct stg_ctx {
     bool axis_z = false;              // every class has easy axis = +z exactly: the specialised Simple RHS applies
     bool axis_z_llgs = false;         // every class has raw easy axis (0,0,rz) and demag (0,0,Nz): specialised LLGS RHS
     // per-env parameters (stg_set_params_per_env): library-owned copies
-    double* env_soa = nullptr;        // records [N][ENV_PREC_DOUBLES] (stg_kernels.hpp: EnvParams)
+    double* env_soa = nullptr;        // records [N][env_layout_doubles(env_layout)] (stg_kernels.hpp: EnvParams)
+    int32_t env_layout = ENV_LAYOUT_CORE;
     uint8_t* env_type = nullptr;      // [N]: the device kind by itself, for the plan kernel (read in env order)
     bool per_env = false;
     int32_t walk_tiles = STG_WALK_TILES_DEFAULT;   // sorted schedule: tiles an XCD group keeps in flight (stg_slot_block)
@@ -370,6 +372,7 @@ static int32_t walk_tiles_from_env() {
 static EnvParams env_params_of(const stg_ctx* ctx) {
     EnvParams e{};
     if (ctx->per_env) e.soa = ctx->env_soa;
+    e.layout = ctx->env_layout;
     e.gamma = ctx->cfg.gamma; e.temperature = ctx->cfg.temperature;
     return e;
 }
@@ -427,6 +430,8 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     stg_ctx* c = new (std::nothrow) stg_ctx();
     if (!c) return fail(STG_E_NOMEM, "out of host memory");
     c->device = device_id; c->N = n_envs; c->env_id0 = env_id0; c->cfg = *cfg;
+    // per-env parameter records hold what this context's kernels read: their solver and torque model are fixed here
+    c->env_layout = cfg->solver == STG_SOLVER_RK45 ? ENV_LAYOUT_LLGS : (cfg->torque_model == 1 ? ENV_LAYOUT_DEV : ENV_LAYOUT_CORE);
     c->walk_tiles = walk_tiles_from_env();
     if (const char* e = std::getenv("STG_HYBRID")) c->hybrid = std::atoi(e);
     if (const char* e = std::getenv("STG_HYBRID_MIN")) c->hybrid_min = std::atoi(e);
@@ -502,14 +507,20 @@ int stg_set_params(stg_ctx* ctx, const stg_device_params* table, int32_t n_class
 // axis flags of a per-env parameter block: flag[0] = some env's easy axis is not exactly +z after normalisation,
 // flag[1] = some env's raw axis or demag factors have x/y components (LLGS specialisation)
 // rows of the caller's structure of arrays -> the library's per-env records (once per stg_set_params_per_env)
-__global__ void stg_env_pack_kernel(const double* soa, const uint8_t* type, const uint8_t* valid, int64_t N, double* rec) {
+__global__ void stg_env_pack_kernel(const double* soa, const uint8_t* type, const uint8_t* valid, int64_t N, double* rec, int layout) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    double* r = rec + i * ENV_PREC_DOUBLES;
-    for (int k = 0; k < STG_NPARAM; ++k) r[k] = soa[(int64_t)k * N + i];
-    r[STG_NPARAM] = (double)type[i];
-    r[STG_NPARAM + 1] = (double)valid[i];
-    for (int k = STG_NPARAM + 2; k < ENV_PREC_DOUBLES; ++k) r[k] = 0.0;
+    // rows of the caller's block = the double fields of stg_device_params in declaration order (include/spintorque_hip.h):
+    // 0 damping, 1 ms, 2 ku, 3 volume, 4 polarization, 5-7 easy_axis, 8-10 demag, 11 a_ex, 12 area, 13 r_p, 14 r_ap, 15-17 ref_m,
+    // 18 r_series, 19 sot_tau_dl, 20 sot_tau_fl, 21-23 sot_sigma, 24 vcma_xi, 25 vcma_td, 26 vcma_vbd, 27-29 shape_demag
+    constexpr int core[15] = {0, 1, 2, 3, 4, 5, 6, 7, 12, 13, 14, 15, 16, 17, 18};
+    constexpr int llgs[4] = {8, 9, 10, 11};
+    constexpr int dev[8] = {19, 20, 21, 22, 23, 24, 25, 26};
+    double* r = rec + i * env_layout_doubles(layout);
+    for (int k = 0; k < 15; ++k) r[k] = soa[(int64_t)core[k] * N + i];
+    r[15] = (double)((int)(type[i] & 3) + 4 * (valid[i] ? 1 : 0));
+    if (layout == ENV_LAYOUT_LLGS) for (int k = 0; k < 4; ++k) r[16 + k] = soa[(int64_t)llgs[k] * N + i];
+    if (layout == ENV_LAYOUT_DEV) for (int k = 0; k < 8; ++k) r[16 + k] = soa[(int64_t)dev[k] * N + i];
 }
 
 __global__ void stg_env_axis_kernel(const double* soa, int64_t N, int32_t* flag) {
@@ -530,7 +541,7 @@ int stg_set_params_per_env(stg_ctx* ctx, const double* soa_params, const uint8_t
         // both buffers or neither: a context is never left with one of them set
         double* soa = nullptr;
         uint8_t* bytes = nullptr;
-        HIP_TRY(hipMalloc(&soa, sizeof(double) * ENV_PREC_DOUBLES * N));
+        HIP_TRY(hipMalloc(&soa, sizeof(double) * env_layout_doubles(ctx->env_layout) * N));
         const hipError_t e2 = hipMalloc(&bytes, N);
         if (e2 != hipSuccess) {
             (void)hipFree(soa);
@@ -540,7 +551,7 @@ int stg_set_params_per_env(stg_ctx* ctx, const double* soa_params, const uint8_t
         ctx->env_type = bytes;
     }
     hipLaunchKernelGGL(stg_env_pack_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, soa_params, dev_type, params_valid,
-                       (int64_t)N, ctx->env_soa);
+                       (int64_t)N, ctx->env_soa, (int)ctx->env_layout);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(ctx->env_type, dev_type, N, hipMemcpyDeviceToDevice));
     // the specialised right-hand sides apply only if EVERY env has the default axis geometry

@@ -43,17 +43,24 @@ struct CfgView {
     int32_t max_steps, n_targets, skip_done;
 };
 
-// Per-env parameters (stg_set_params_per_env): ONE 256-byte record per env, env index major -- the STG_NPARAM doubles of
-// stg_device_params in declaration order, then the device type and the host-evaluated validity flag as doubles.  The
-// caller hands them over as rows of a structure of arrays; the library transposes once.  Rows were the wrong layout for the
-// step kernel for the same reason as for the state: under the duration-sorted schedule a lane's env
-// is anywhere in its tile, so each of its 30 row elements was an 8-byte read out of its own 64-byte request -- measured 1.9
-// KB of HBM traffic per env-step for 242 B of parameters (profiles/r03e: 7.1 x the algorithmic bytes); a record is four
-// whole 64-byte lines whatever the schedule.
-constexpr int ENV_PREC_DOUBLES = 32;
+// Per-env parameters (stg_set_params_per_env): ONE record per env, env index major, holding only the fields the context's solver and
+// torque model read (the caller hands over all STG_NPARAM rows of a structure of arrays; the library packs once):
+//   core, 16 doubles = 128 B (the fixed-step solvers with the reference RHS -- what SpinTorqueEnv runs):
+//     damping, ms, ku, volume, polarization, easy_axis[3], area, r_p, r_ap, ref_m[3], r_series, dev_type + 4 * params_valid
+//   ENV_LAYOUT_LLGS (RK45), 20 doubles = 160 B: core + demag[3], a_ex
+//   ENV_LAYOUT_DEV (fixed-step solvers with the device-physics torque model), 24 doubles = 192 B: core + sot_tau_dl, sot_tau_fl,
+//     sot_sigma[3], vcma_xi, vcma_td, vcma_vbd
+// (shape_demag is the array env's.)  Rows were the wrong layout for the step kernel for the same reason as for the state (DESIGN.md
+// section 2): under the duration-sorted schedule a lane's env is anywhere in its tile, so each of its row elements was an 8-byte read
+// out of its own 64-byte request -- measured 1.9 KB of HBM traffic per env-step for 242 B of parameters (profiles/r03e); a record is
+// whole 32-byte sectors whatever the schedule.  Rounds 2-3 kept all 30 fields + 2 in a 256-byte record: 1.92 x the algorithmic bytes
+// of the per-env cfg4 row (SURVEY 8d prices the parameters at 112 B); the core record makes it 128 B.
+enum : int { ENV_LAYOUT_CORE = 0, ENV_LAYOUT_LLGS = 1, ENV_LAYOUT_DEV = 2 };
+__host__ __device__ constexpr int env_layout_doubles(int layout) { return layout == ENV_LAYOUT_CORE ? 16 : (layout == ENV_LAYOUT_LLGS ? 20 : 24); }
 struct EnvParams {
-    const double* soa;        // records [N][ENV_PREC_DOUBLES] or nullptr (the name is historical: "per-env parameters present")
+    const double* soa;        // records [N][env_layout_doubles(layout)] or nullptr (the name is historical: "per-env parameters present")
     double gamma, temperature;
+    int32_t layout;           // ENV_LAYOUT_* the records were packed in (= what the context's solver / torque model select)
 };
 
 struct StepArgs {
@@ -128,40 +135,55 @@ __device__ __forceinline__ void store_state(const StateView& s, int64_t i, const
     p[3] = make_double2(etot, __longlong_as_double((long long)w));
 }
 
-__device__ __forceinline__ void load_env_params(const EnvParams& e, int64_t N, int64_t i, stg_device_params& p) {
-    double q[ENV_PREC_DOUBLES];
-    const double2* src = reinterpret_cast<const double2*>(e.soa + i * ENV_PREC_DOUBLES);
+// One env's record -> the reference-style parameter struct (fields that are not in the layout get the defaults of
+// devices.flatten_params; the derived constants built from them belong to rows this kernel never reads).
+template <int LAYOUT>
+__device__ __forceinline__ void load_env_params(const EnvParams& e, int64_t i, stg_device_params& p) {
+    constexpr int ND = env_layout_doubles(LAYOUT);
+    double q[ND];
+    const double2* src = reinterpret_cast<const double2*>(e.soa + i * ND);
 #pragma unroll
-    for (int k = 0; k < ENV_PREC_DOUBLES / 2; ++k) { const double2 v = src[k]; q[2 * k] = v.x; q[2 * k + 1] = v.y; }
-    int r = 0;
-    auto nx = [&]() { const double v = q[r]; ++r; return v; };
-    p.damping = nx(); p.ms = nx(); p.ku = nx(); p.volume = nx(); p.polarization = nx();
-    for (int k = 0; k < 3; ++k) p.easy_axis[k] = nx();
-    for (int k = 0; k < 3; ++k) p.demag[k] = nx();
-    p.a_ex = nx(); p.area = nx(); p.r_p = nx(); p.r_ap = nx();
-    for (int k = 0; k < 3; ++k) p.ref_m[k] = nx();
-    p.r_series = nx(); p.sot_tau_dl = nx(); p.sot_tau_fl = nx();
-    for (int k = 0; k < 3; ++k) p.sot_sigma[k] = nx();
-    p.vcma_xi = nx(); p.vcma_td = nx(); p.vcma_vbd = nx();
-    for (int k = 0; k < 3; ++k) p.shape_demag[k] = nx();
-    p.dev_type = (int32_t)q[STG_NPARAM];
-    p.params_valid = (int32_t)q[STG_NPARAM + 1];
+    for (int k = 0; k < ND / 2; ++k) { const double2 v = src[k]; q[2 * k] = v.x; q[2 * k + 1] = v.y; }
+    p.damping = q[0]; p.ms = q[1]; p.ku = q[2]; p.volume = q[3]; p.polarization = q[4];
+    for (int k = 0; k < 3; ++k) p.easy_axis[k] = q[5 + k];
+    p.area = q[8]; p.r_p = q[9]; p.r_ap = q[10];
+    for (int k = 0; k < 3; ++k) p.ref_m[k] = q[11 + k];
+    p.r_series = q[14];
+    const int tv = (int)q[15];
+    p.dev_type = tv & 3;
+    p.params_valid = tv >> 2;
+    p.demag[0] = 0.0; p.demag[1] = 0.0; p.demag[2] = 1.0; p.a_ex = 20e-12;
+    p.sot_tau_dl = 0.0; p.sot_tau_fl = 0.0; p.sot_sigma[0] = 0.0; p.sot_sigma[1] = 1.0; p.sot_sigma[2] = 0.0;
+    p.vcma_xi = 0.0; p.vcma_td = 1.0; p.vcma_vbd = 1.0;
+    for (int k = 0; k < 3; ++k) p.shape_demag[k] = 0.0;
+    if constexpr (LAYOUT == ENV_LAYOUT_LLGS) {
+        for (int k = 0; k < 3; ++k) p.demag[k] = q[16 + k];
+        p.a_ex = q[19];
+    }
+    if constexpr (LAYOUT == ENV_LAYOUT_DEV) {
+        p.sot_tau_dl = q[16]; p.sot_tau_fl = q[17];
+        for (int k = 0; k < 3; ++k) p.sot_sigma[k] = q[18 + k];
+        p.vcma_xi = q[21]; p.vcma_td = q[22]; p.vcma_vbd = q[23];
+    }
 }
-static_assert(STG_NPARAM + 2 <= ENV_PREC_DOUBLES, "per-env record size");
 
 // Returns this lane's row of derived constants.  One class: the (wave-uniform) global table row, which the compiler
 // turns into scalar loads.  MULTI: the class table staged in LDS, or -- per-env parameters -- a row per lane derived
 // here from the env's own record (the LDS block holds exactly 64 rows: per-env launches use 64 integrating lanes per
 // workgroup; lanes of a producer wavefront read the row of the integrating lane they mirror).
+// `layout`: the per-env record layout -- a compile-time constant in the step kernel (its solver and torque model fix it), the
+// context's value in the reset kernel.
 template <bool MULTI>
 __device__ __forceinline__ const double* class_row(const double* ctab, const uint8_t* cls, int32_t ncls, int64_t i,
-                                                   bool in_range, double* lds, const EnvParams& ep, int64_t N) {
+                                                   bool in_range, double* lds, const EnvParams& ep, int64_t N, int layout = ENV_LAYOUT_CORE) {
     if (MULTI) {
         if (ep.soa) {
             const int lane = (int)(threadIdx.x & 63u);
             if (threadIdx.x < 64 && in_range) {
                 stg_device_params p;
-                load_env_params(ep, N, i, p);
+                if (layout == ENV_LAYOUT_CORE) load_env_params<ENV_LAYOUT_CORE>(ep, i, p);
+                else if (layout == ENV_LAYOUT_LLGS) load_env_params<ENV_LAYOUT_LLGS>(ep, i, p);
+                else load_env_params<ENV_LAYOUT_DEV>(ep, i, p);
                 derive_row(p, ep.gamma, ep.temperature, lds + lane * C_COUNT);
             }
             __syncthreads();
@@ -625,7 +647,8 @@ stg_step_kernel(const StepArgs a) {
     // duration-sorted schedule: slot j of the launch integrates env perm[j], so the 64 lanes of a wavefront have
     // (nearly) equal trip counts; all state and outputs stay at the env's own index
     const int64_t i = live ? (a.perm ? (int64_t)a.perm[lane_slot] : lane_slot) : 0;
-    const double* row = class_row<MULTI>(a.ctab, a.cls, a.ncls, i, live, s_tab, a.ep, a.N);
+    constexpr int ENV_LAYOUT = SOLVER == STG_SOLVER_RK45 ? ENV_LAYOUT_LLGS : (DEVPHYS ? ENV_LAYOUT_DEV : ENV_LAYOUT_CORE);
+    const double* row = class_row<MULTI>(a.ctab, a.cls, a.ncls, i, live, s_tab, a.ep, a.N, ENV_LAYOUT);
     // Lanes without an env: the one-wavefront form has no rendezvous after this point and lets them go; in the
     // wave-specialised form they stay (inert) because every wavefront of the workgroup takes part in every s_barrier.
     if (!PC && !live) return;

@@ -1318,6 +1318,13 @@ def test_per_env_parameters(stg, solver, thermal):
         if tilt:
             ax = np.tile(np.array([0.0, 0.0, 1.0]), (n, 1)); ax[:, :2] = rng.normal(0, 0.2, (n, 2))
             ov["easy_axis"] = ax
+        if solver == "rk45":
+            # the fields only LLGSSolver reads (llgs_solver.py:200-209) -- the 20-double record layout of the RK45 contexts
+            dm = np.tile(np.array([0.0, 0.0, 1.0]), (n, 1)); dm[:, 2] = rng.uniform(0.8, 1.0, n)
+            if tilt:
+                dm[:, 0] = rng.uniform(0.0, 0.1, n); dm[:, 1] = rng.uniform(0.0, 0.1, n)
+            ov["demag_factors"] = dm
+            ov["exchange_constant"] = np.where(rng.integers(0, 2, n) == 0, 0.0, rng.uniform(1e-11, 3e-11, n))
         return ov
 
     def dicts(n, ov):
@@ -1371,6 +1378,53 @@ def test_per_env_parameters(stg, solver, thermal):
         m = env.get_state()["m"]
         assert torch.isfinite(obs).all() and torch.all(torch.abs(torch.linalg.norm(m, dim=0) - 1) < 1e-14)
         env.close()
+
+
+@pytest.mark.parametrize("solver", ["rk4", "euler"])
+def test_per_env_parameters_device_physics_mixed_types(stg, solver):
+    """Per-env parameter records of a device-physics context (24-double layout: core + SOT factors / sigma + VCMA coefficients,
+    csrc/stg_kernels.hpp: EnvParams) over a mixed STT / SOT / VCMA batch: bit-identical to the class-table path with one class per
+    env, whose constants the host derives (same arithmetic, sot_mram.py:61-72,163-194, vcma_mram.py:122-147)."""
+    from helpers import unit_rows
+    rng = np.random.default_rng(12)
+    n = 63
+    fac = stg.DeviceFactory()
+    vol = 8.75e-11
+    bases = []
+    for t in ("stt_mram", "sot_mram", "vcma_mram"):
+        d = fac.get_default_parameters(t); d.update(polarization=0.7, volume=vol)
+        bases.append(d)
+    types = ["stt_mram", "sot_mram", "vcma_mram"]
+    cls = rng.integers(0, 3, n).astype(np.uint8)
+    ov = dict(volume=vol * 10 ** rng.uniform(-0.2, 0.2, n), damping=10 ** rng.uniform(-2.2, -1.2, n),
+              uniaxial_anisotropy=rng.uniform(8e5, 1.2e6, n), polarization=rng.uniform(0.5, 0.9, n),
+              resistance_parallel=rng.uniform(900, 1300, n))
+    per_class = []
+    for i in range(n):
+        d = dict(bases[cls[i]])
+        for k, v in ov.items():
+            d[k] = float(v[i])
+        per_class.append(d)
+    m0 = unit_rows(rng, n)
+    tgt = np.where(rng.integers(0, 2, (n, 1)) == 0, 1.0, -1.0) * np.array([[0.0, 0.0, 1.0]])
+    acts = [_uniform_actions(2e6, 1e-10, 3e-10)(rng, n, k) for k in range(2)]
+    kw = dict(include_thermal_fluctuations=False, solver=solver, seed=5, torque_model="device")
+    e1 = stg.SpinTorqueVecEnv(n, diagnostics=True, device_type=types, device_params=bases, class_index=cls, per_env_params=ov, **kw)
+    e2 = stg.SpinTorqueVecEnv(n, diagnostics=True, device_type=[types[c] for c in cls], device_params=per_class,
+                              class_index=np.arange(n).astype(np.uint8), **kw)
+    outs = []
+    for env in (e1, e2):
+        env.reset(options={"initial_state": m0, "target_state": tgt})
+        rec = []
+        for a in acts:
+            o, r, te, tr, info = env.step(torch.from_numpy(a))
+            rec.append((o.clone(), info["reward_f64"].clone(), info["status"].clone(), info["energy"].clone(), env.get_state()["m"].clone()))
+        outs.append(rec)
+        env.close()
+    for k, (x, y) in enumerate(zip(*outs)):
+        for j, (p, q) in enumerate(zip(x, y)):
+            assert torch.equal(p, q), (solver, k, j)
+    assert float((outs[0][-1][4] - torch.from_numpy(m0.T).cuda()).abs().max()) > 1e-3       # (the pulses did move the magnetisation)
 
 
 def test_switching_statistics_independent_streams(stg):
