@@ -18,7 +18,18 @@ __device__ __forceinline__ bool ok(uint64_t byte_off, uint64_t len) {
     atomicAdd(&g_violations, 1ull);
     return false;
 }
-__device__ __forceinline__ uint64_t scatter(uint64_t i) { return (i * 0x9E3779B1ull + 12345ull) & (NREC - 1); }   // odd multiplier: a permutation
+// odd multiplier: a permutation of [0, NREC).  The masked value goes through an opaque register barrier: hipcc 7.2 (-O2, gfx950) was
+// seen to turn `(x & 0xFFFFFF) * 56 + base` into v_mul_lo_u32 / v_add_u32 / v_mad_u64_u32 WITHOUT the mask (the 24-bit-multiply
+// combine dropped it and the 64-bit multiply-add does not truncate) and then to remove the bounds check as provably true -- the first
+// two runs of this probe wrote up to 240 GB past the buffer and faulted the GPU (round 4, profiles/EXPERIMENTS.md).  Check the ISA
+// (`v_and_b32 ..., 0xffffff`) before running it.
+__device__ __forceinline__ uint64_t scatter(uint64_t i) {
+    uint32_t r = (uint32_t)((i * 0x9E3779B1ull + 12345ull) & (NREC - 1));
+    asm volatile("" : "+v"(r));
+    r &= (uint32_t)(NREC - 1);
+    asm volatile("" : "+v"(r));
+    return (uint64_t)r;
+}
 
 // every ACTIVE lane reads one whole 64-byte record (4 x 16 B) at a scattered position; `active` of the 64 lanes of a wavefront take part
 template <int ACTIVE>
