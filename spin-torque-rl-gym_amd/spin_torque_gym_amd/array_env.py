@@ -276,6 +276,29 @@ class SpinTorqueArrayEnv(_EnvBase):
         self.current_pattern = None
         self.step_count, self.total_energy = 0, 0.0
         self.episode_history: List[Dict[str, Any]] = []
+        self.renderer = None                  # the persistent figure of render('human') (array_env.py:149-151, 608-620)
+        if render_mode == "human":
+            from .render import HumanFigure
+            self.renderer = HumanFigure("array")
+
+    # -- rendering (array_env.py:594-708): host-side matplotlib, optional (spin_torque_gym_amd/render.py) --------------
+    def render(self, mode: Optional[str] = None):
+        """'human': m_z maps of the current and the target pattern, similarity (with the success threshold) and energy per step
+        from `episode_history`, one persistent figure, returns None; 'rgb_array': the two maps as uint8 [H, W, 3]."""
+        mode = self.render_mode if mode is None else mode
+        if mode is None:
+            return None
+        if mode not in ("human", "rgb_array"):
+            raise ValueError(f"Unsupported render mode: {mode}")
+        if self.current_pattern is None:
+            raise RuntimeError("Environment must be reset before calling render")
+        from . import render as _render
+        if mode == "rgb_array":
+            return _render.array_rgb(self, self._similarity())
+        if self.renderer is None:
+            self.renderer = _render.HumanFigure("array")
+        self.renderer.draw(self)
+        return None
 
     def seed(self, seed: Optional[int] = None):
         self._np_random, s = _np_random(seed)
@@ -369,4 +392,7 @@ class SpinTorqueArrayEnv(_EnvBase):
                 "coupling_type": self.coupling_type, "coupling_strength": self.coupling_strength}
 
     def close(self):
+        if self.renderer is not None:
+            self.renderer.close()
+            self.renderer = None
         self._vec.close()

@@ -386,7 +386,10 @@ class SpinTorqueEnv(_EnvBase):
         self._solve_count = 0
         self._solve_time = [0.0, 0.0]         # last, total (wall time of the synchronous N = 1 step)
         self.profiler = _TimerTable()
-        self.renderer = None
+        self.renderer = None                  # the persistent figure of render('human') (spin_torque_env.py:152-154, 570-587)
+        if render_mode == "human":
+            from .render import HumanFigure
+            self.renderer = HumanFigure("macrospin")
 
     # -- seeding (spin_torque_env.py:694-697) -------------------------------------------------------------
     def seed(self, seed: Optional[int] = None):
@@ -478,36 +481,29 @@ class SpinTorqueEnv(_EnvBase):
                 "magnetization_magnitude": float(np.linalg.norm(self.current_magnetization)) if self.current_magnetization is not None else 0.0,
                 "device_type": self.device_type, "episode_history": self.episode_history.copy()}
 
-    # -- rendering (spin_torque_env.py:556-684): host-side matplotlib, optional --------------------------------
+    # -- rendering (spin_torque_env.py:556-684): host-side matplotlib, optional (spin_torque_gym_amd/render.py) -------
     def render(self, mode: Optional[str] = None):
+        """'human': the reference's four-panel figure (3-D magnetisation arrows in the unit sphere; energy, alignment and current
+        histories), one persistent figure redrawn in place, returns None; 'rgb_array': the x-y projection as uint8 [H, W, 3]."""
         mode = self.render_mode if mode is None else mode
         if mode is None:
             return None
         if mode not in ("human", "rgb_array"):
             raise ValueError(f"Unsupported render mode: {mode}")
-        try:
-            import matplotlib
-            matplotlib.use("Agg", force=False)
-            import matplotlib.pyplot as plt
-        except ImportError:
-            warnings.warn("Matplotlib not available, rendering disabled")
-            return None
-        fig, ax = plt.subplots(figsize=(8, 6))
-        m, t = self.current_magnetization, self.target_magnetization
-        ax.quiver(0, 0, m[0], m[1], color="red", scale=1, label="Current")
-        ax.quiver(0, 0, t[0], t[1], color="blue", scale=1, label="Target")
-        ax.add_patch(plt.Circle((0, 0), 1, fill=False, color="gray", alpha=0.5))
-        ax.set_xlim([-1.5, 1.5])
-        ax.set_ylim([-1.5, 1.5])
-        ax.set_aspect("equal")
-        ax.legend()
-        ax.set_title(f"Step {self.step_count}: Alignment = {float(np.dot(m, t)):.3f}")
-        fig.canvas.draw()
-        rgb = np.asarray(fig.canvas.buffer_rgba())[..., :3].copy()
-        plt.close(fig)
-        return rgb if mode == "rgb_array" else None
+        from . import render as _render
+        if self.current_magnetization is None:
+            raise RuntimeError("Environment must be reset before calling render")
+        if mode == "rgb_array":
+            return _render.macrospin_rgb(self)
+        if self.renderer is None:
+            self.renderer = _render.HumanFigure("macrospin")
+        self.renderer.draw(self)
+        return None
 
     def close(self):
+        if self.renderer is not None:
+            self.renderer.close()
+            self.renderer = None
         self._vec.close()
 
     # -- introspection (spin_torque_env.py:699-745) ------------------------------------------------------------
