@@ -757,9 +757,14 @@ def placement_report(meas):
     if not pl:
         return None
     db = [p["simd_double_booked"] for p in pl]
+    mean_of = lambda key: round(float(np.mean([p[key] for p in pl if p.get(key) is not None])), 4) if any(p.get(key) is not None for p in pl) else None
     return {"workgroups": pl[-1]["workgroups"], "waves_per_workgroup": pl[-1]["waves_per_workgroup"], "simds_used": [p["simds_used"] for p in pl],
             "simd_double_booked": db, "simd_double_booked_mean": round(float(np.mean(db)), 2), "kernel_ms": meas.get("kernel_ms"),
-            "integrating_wavefronts_per_simd_last_launch": pl[-1]["integrating_per_simd"]}
+            "integrating_wavefronts_per_simd_last_launch": pl[-1]["integrating_per_simd"],
+            # from the wavefronts' start / retire times: mean share of the launch during which a SIMD held an integrating wavefront,
+            # and the share of the launch left once 90 % of the SIMDs have retired their last one (the makespan's tail)
+            "simd_busy_frac": mean_of("simd_busy_frac"), "last_simd_alone_frac": mean_of("last_simd_alone_frac"),
+            "span_us": mean_of("span_us")}
 
 
 def roofline_hbm(meas, bytes_per_launch, pmc_row, pmc_src, extra=None):

@@ -234,15 +234,21 @@ int stg_set_state(stg_ctx* ctx, const double* m, const double* target, const dou
  * (utils/monitoring.py:30-268, utils/robust_solver.py:311-328).  Synchronises the device. */
 int stg_get_counters(stg_ctx* ctx, uint64_t* out, int32_t reset);
 
-/* Where the dispatcher placed the wavefronts of a recent step launch (ABI v4).  The launch schedules of this library (which 64-env
- * block a wavefront takes) are speed heuristics built on observed dispatcher behaviour; every step launch records, once per
- * wavefront, the SIMD it ran on, so that a caller (bench.py: `simd_double_booked`) can tell "this run got an unlucky placement" from
- * "this build is slower".  launches_back = 0 addresses the most recent step launch of the context, 1 the one before, ... (the last 32
- * are kept).  out [host] receives one word per wavefront, index = workgroup * waves_per_workgroup + wavefront (the first 4096
- * wavefronts of the launch): bits 0-15 = HW_ID[15:0] (bits 5:4 SIMD, 11:8 CU, 12 SH, 15:13 SE), bits 16-19 = XCC_ID, bit 20 = producer
- * wavefront of a wave-specialised pair, bit 31 = valid (a workgroup beyond the batch leaves 0).  Returns the number of words written
- * (<= cap) or a negative error.  Synchronises the device.  The reference has no counterpart (its bookkeeping is host-side:
- * utils/monitoring.py:30-268). */
+/* Where the dispatcher placed the wavefronts of a recent step launch, and when each ran (ABI v4).  The launch schedules of this
+ * library (which 64-env block a wavefront takes) are speed heuristics built on observed dispatcher behaviour; every step launch
+ * records, once per wavefront, the SIMD it ran on and the real-time counter when it started and when it retired, so that a caller
+ * (bench.py: `roofline.placement`) can tell "this run got an unlucky placement" from "this build is slower" and see the per-SIMD
+ * timeline of a launch.  launches_back = 0 addresses the most recent step launch of the context, 1 the one before, ... (the last 32
+ * are kept).  out [host] receives STG_PLACEMENT_WORDS_PER_WAVE words per wavefront, wavefront index = workgroup *
+ * waves_per_workgroup + wavefront (the first 4096 wavefronts of the launch; cap = size of out in words):
+ *   word 0: bits 0-15 = HW_ID[15:0] (bits 5:4 SIMD, 11:8 CU, 12 SH, 15:13 SE), bits 16-19 = XCC_ID, bit 20 = producer wavefront of a
+ *           wave-specialised pair, bit 31 = valid (a workgroup beyond the batch leaves 0)
+ *   word 1, word 2: low 32 bits of the 100 MHz real-time counter (s_memrealtime) at the wavefront's start / when it retired (0: the
+ *           wavefront had no env)
+ * Returns the number of WAVEFRONTS written or a negative error.  Synchronises the device.  Cost per launch: two s_getreg, two
+ * s_memrealtime and three 4-byte stores per wavefront, nothing inside any loop.  The reference has no counterpart (its bookkeeping is
+ * host-side: utils/monitoring.py:30-268). */
+#define STG_PLACEMENT_WORDS_PER_WAVE 3
 int stg_get_placement(stg_ctx* ctx, int32_t launches_back, uint32_t* out, int32_t cap, int32_t* n_workgroups,
                       int32_t* waves_per_workgroup);
 

@@ -825,11 +825,13 @@ int stg_get_placement(stg_ctx* ctx, int32_t launches_back, uint32_t* out, int32_
     const uint64_t seq = ctx->launch_seq - 1 - (uint64_t)launches_back;
     HIP_TRY(hipMemcpy(h, ctx->placement + (size_t)(seq % PLACEMENT_RING) * PLACEMENT_WORDS, sizeof(h), hipMemcpyDeviceToHost));
     const int64_t waves = (int64_t)h[0] * (int64_t)h[1];
-    const int32_t n = (int32_t)(waves < PLACEMENT_CAP ? waves : PLACEMENT_CAP);
+    int32_t n = (int32_t)(waves < PLACEMENT_CAP ? waves : PLACEMENT_CAP);
+    if (n > cap / STG_PLACEMENT_WORDS_PER_WAVE) n = cap / STG_PLACEMENT_WORDS_PER_WAVE;
     if (n_workgroups) *n_workgroups = (int32_t)h[0];
     if (waves_per_workgroup) *waves_per_workgroup = (int32_t)h[1];
-    for (int32_t j = 0; j < n && j < cap; ++j) out[j] = h[2 + j];
-    return n < cap ? n : cap;
+    static_assert(STG_PLACEMENT_WORDS_PER_WAVE == PLACEMENT_ENTRY, "entry size of the placement table");
+    std::memcpy(out, h + 2, sizeof(uint32_t) * (size_t)n * PLACEMENT_ENTRY);
+    return n;
 }
 
 int stg_thermal_normals(stg_ctx* ctx, uint32_t env_step, uint32_t call0, int32_t n_calls, double* z, void* stream) {

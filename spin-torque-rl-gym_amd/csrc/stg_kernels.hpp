@@ -321,11 +321,15 @@ __device__ __forceinline__ void write_record_obs(void* base, int64_t i, const V3
 // (workgroup b on XCD b % 8, a CU takes workgroups q, q + 32, ..., which wavefronts share a SIMD); the release build records what a
 // launch actually got so that a slow run can be told from a slow build: one lane of every wavefront stores its HW_ID / XCC_ID once
 // per launch -- two s_getreg_b32 and one 4-byte store per wavefront, nothing in any loop.
-//   table[0] = workgroups of the launch, table[1] = wavefronts per workgroup, table[2 + b * wpw + wave] = entry (first
-//   PLACEMENT_CAP wavefronts): bits 0-15 HW_ID[15:0] (wave slot 3:0, SIMD 5:4, pipe 7:6, CU 11:8, SH 12, SE 15:13), bits 16-19
-//   XCC_ID, bit 20 producer wavefront of a wave-specialised pair, bit 31 valid.
+//   table[0] = workgroups of the launch, table[1] = wavefronts per workgroup, then PLACEMENT_ENTRY words per wavefront (index
+//   b * wpw + wave, the first PLACEMENT_CAP wavefronts):
+//     [0] bits 0-15 HW_ID[15:0] (wave slot 3:0, SIMD 5:4, pipe 7:6, CU 11:8, SH 12, SE 15:13), bits 16-19 XCC_ID, bit 20 producer
+//         wavefront of a wave-specialised pair, bit 31 valid
+//     [1], [2] the low 32 bits of the 100 MHz real-time counter (s_memrealtime) when the wavefront started / retired (0: it had no
+//         env): with [0] the per-SIMD timeline of the launch -- who ran where, next to whom, for how long
 constexpr int PLACEMENT_CAP = 4096;
-constexpr int PLACEMENT_WORDS = 2 + PLACEMENT_CAP;
+constexpr int PLACEMENT_ENTRY = 3;
+constexpr int PLACEMENT_WORDS = 2 + PLACEMENT_ENTRY * PLACEMENT_CAP;
 constexpr int PLACEMENT_RING = 32;        // tables kept: one per launch, the last PLACEMENT_RING launches
 __device__ __forceinline__ void record_placement(uint32_t* table, int wave, int lane, bool producer) {
     if (table == nullptr || lane != 0) return;
@@ -334,7 +338,17 @@ __device__ __forceinline__ void record_placement(uint32_t* table, int wave, int 
     if (idx >= (uint32_t)PLACEMENT_CAP) return;
     const uint32_t hw = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);      // HW_REG_HW_ID bits 15:0
     const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);     // HW_REG_XCC_ID bits 3:0
-    table[2 + idx] = (hw & 0xFFFFu) | ((xcc & 0xFu) << 16) | (producer ? (1u << 20) : 0u) | (1u << 31);
+    uint32_t* e = table + 2 + PLACEMENT_ENTRY * idx;
+    e[0] = (hw & 0xFFFFu) | ((xcc & 0xFu) << 16) | (producer ? (1u << 20) : 0u) | (1u << 31);
+    e[1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    e[2] = 0u;
+}
+// ... and when the wavefront retires (every exit of a wavefront that had work)
+__device__ __forceinline__ void record_retired(uint32_t* table, int wave, int lane) {
+    if (table == nullptr || lane != 0) return;
+    const uint32_t wpw = blockDim.x >> 6, idx = blockIdx.x * wpw + (uint32_t)wave;
+    if (idx >= (uint32_t)PLACEMENT_CAP) return;
+    table[2 + PLACEMENT_ENTRY * idx + 2] = (uint32_t)__builtin_amdgcn_s_memrealtime();
 }
 
 constexpr int COUNTER_STRIPES = 1024;     // copies of the on-device counters (one 64-byte line each)
@@ -671,6 +685,7 @@ stg_step_kernel(const StepArgs a) {
             const RngKey rk{a.c.seed, env_id, s_rng[cw * 64 + lane]};
             produce_normals<NT, FIELD, DEPTH, BARRIER>(s_norm, s_hs, lane, rk, n_first, n_chunk, ghs);
         }
+        record_retired(a.placement, wave, lane);
         return;
     }
 
@@ -725,6 +740,7 @@ stg_step_kernel(const StepArgs a) {
         env_step_tail(a, i, ko, wr, live, lane_solves, row, env_id, m, tgt, etot, step, rng, done, J, T, so, c_steps, c_sub, c_noop);
     }
     if (live) store_state(a.s, i, m, tgt, etot, step, rng, done);
+    record_retired(a.placement, wave, lane);
     // on-device metrics (the reference's EnvironmentMonitor/solver stats are host-side bookkeeping): one atomic per
     // counter per wavefront, into one of COUNTER_STRIPES copies
     const int ci = PC ? wave : cw;                                  // (this wavefront's counter triple)
@@ -862,6 +878,7 @@ __global__ void __launch_bounds__(WGW * 64) stg_step_refill_kernel(const StepArg
         if (__ballot(has_env) == 0ull && q_next >= q_len) break;
     }
     prof.stop(L.attempts);
+    record_retired(a.placement, wave, lane);
     wave_add3(a.counters + (size_t)((blockIdx.x * WGW + wave) % COUNTER_STRIPES) * COUNTER_STRIDE, s_cnt + wave * 3, c_steps, c_sub, c_noop);
 }
 

@@ -385,28 +385,68 @@ class HipBackend:
         return {"env_steps": int(out[0]), "work_units": int(out[1]), "noop_steps": int(out[3])}
 
     PLACEMENT_CAP = 4096
+    PLACEMENT_ENTRY = 3                   # STG_PLACEMENT_WORDS_PER_WAVE
 
-    def placement(self, launches_back=0):
-        """Where the dispatcher put the wavefronts of a recent step launch (stg_get_placement; 0 = the latest, up to 31 back):
-        dict(workgroups, waves_per_workgroup, simds_used, integrating_per_simd (histogram {count: SIMDs}), simd_double_booked).
-        `simd_double_booked` = SIMDs that held two or more INTEGRATING wavefronts of the launch -- for the launches scheduled
-        for one integrating wavefront per SIMD (up to 65 536 envs; the wave-specialised pairs) it should be 0, and every such
-        SIMD costs the launch the time of its two wavefronts back to back.  Synchronises the device."""
-        out = (C.c_uint32 * self.PLACEMENT_CAP)()
+    def placement(self, launches_back=0, raw=False):
+        """Where the dispatcher put the wavefronts of a recent step launch and when each ran (stg_get_placement; 0 = the latest, up to
+        31 back): dict(workgroups, waves_per_workgroup, waves_recorded, simds_used, integrating_per_simd (histogram {count: SIMDs}),
+        simd_double_booked, span_us, simd_busy_frac, last_simd_alone_frac).
+        `simd_double_booked` = SIMDs that held two or more INTEGRATING wavefronts of the launch -- for the launches scheduled for one
+        integrating wavefront per SIMD (up to 65 536 envs; the wave-specialised pairs) it should be 0, and every such SIMD costs the
+        launch the time of its two wavefronts back to back.  From the start / retire times: `span_us` = first start to last retire;
+        `simd_busy_frac` = mean over the 1024 SIMDs of the share of that span during which the SIMD held at least one integrating
+        wavefront; `last_simd_alone_frac` = share of the span left once 90 % of the SIMDs in use have retired their last integrating
+        wavefront (the tail a makespan-bound launch ends with).  raw=True adds the arrays (`where`, `producer`, `t0_us`, `t1_us` per recorded wavefront).
+        Synchronises the device."""
+        words = self.PLACEMENT_CAP * self.PLACEMENT_ENTRY
+        out = (C.c_uint32 * words)()
         nwg, wpw = C.c_int32(), C.c_int32()
-        n = self.lib.stg_get_placement(self._ctx, int(launches_back), out, self.PLACEMENT_CAP, C.byref(nwg), C.byref(wpw))
+        n = self.lib.stg_get_placement(self._ctx, int(launches_back), out, words, C.byref(nwg), C.byref(wpw))
         if n < 0:
             _lib.check(n)
-        w = np.frombuffer(out, dtype=np.uint32, count=n).copy()
-        w = w[(w >> 31) == 1]
+        e = np.frombuffer(out, dtype=np.uint32, count=n * self.PLACEMENT_ENTRY).reshape(n, self.PLACEMENT_ENTRY).copy()
+        e = e[(e[:, 0] >> 31) == 1]
+        w = e[:, 0]
         simd = (w & 0xFFFF) >> 4 & 3
         where = ((w >> 16 & 0xF).astype(np.int64) << 12) | ((w >> 8 & 0xFF).astype(np.int64) << 2) | simd      # (xcc, se/sh/cu, simd)
-        integ = where[(w >> 20 & 1) == 0]
+        prod = (w >> 20 & 1) == 1
+        integ = where[~prod]
         _, cnt = np.unique(integ, return_counts=True)
         hist = {int(k): int(v) for k, v in zip(*np.unique(cnt, return_counts=True))}
-        return {"workgroups": int(nwg.value), "waves_per_workgroup": int(wpw.value), "waves_recorded": int(len(w)),
-                "simds_used": int(len(np.unique(where))), "integrating_per_simd": hist,
-                "simd_double_booked": int((cnt >= 2).sum())}
+        res = {"workgroups": int(nwg.value), "waves_per_workgroup": int(wpw.value), "waves_recorded": int(len(w)),
+               "simds_used": int(len(np.unique(where))), "integrating_per_simd": hist,
+               "simd_double_booked": int((cnt >= 2).sum())}
+        # timeline (100 MHz ticks, 32-bit wrap-safe differences against the earliest start)
+        ran = e[:, 2] != 0
+        if ran.any():
+            t0 = e[ran, 1].astype(np.int64)
+            base = int(t0.min()) if (int(t0.max()) - int(t0.min())) < (1 << 31) else int(t0[0])
+            s0 = ((e[:, 1].astype(np.int64) - base) & 0xFFFFFFFF).astype(np.float64) * 0.01
+            s1 = ((e[:, 2].astype(np.int64) - base) & 0xFFFFFFFF).astype(np.float64) * 0.01
+            s0, s1 = np.where(ran, s0, 0.0), np.where(ran, s1, 0.0)
+            sel = ran & ~prod
+            span = float(s1[sel].max() - s0[sel].min()) if sel.any() else 0.0
+            busy = {}
+            for k in np.unique(where[sel]):           # union of the integrating wavefronts' intervals per SIMD
+                iv = sorted(zip(s0[sel & (where == k)], s1[sel & (where == k)]))
+                tot, cur_a, cur_b = 0.0, iv[0][0], iv[0][1]
+                for a_, b_ in iv[1:]:
+                    if a_ > cur_b:
+                        tot += cur_b - cur_a
+                        cur_a, cur_b = a_, b_
+                    else:
+                        cur_b = max(cur_b, b_)
+                busy[int(k)] = (tot + cur_b - cur_a, cur_b)
+            n_simd = 1024
+            ends = np.sort(np.array([v[1] for v in busy.values()]))
+            res["span_us"] = round(span, 2)
+            res["simd_busy_frac"] = round(sum(v[0] for v in busy.values()) / (n_simd * span), 4) if span > 0 else None
+            # from the moment 90 % of the SIMDs in use have retired their last integrating wavefront the launch runs on a tenth of them
+            t90 = float(ends[max(int(0.9 * len(ends)) - 1, 0)])
+            res["last_simd_alone_frac"] = round(max(0.0, float(ends[-1]) - t90) / span, 4) if span > 0 else None
+            if raw:
+                res.update(where=where, producer=prod, t0_us=s0, t1_us=s1)
+        return res
 
     def thermal_normals(self, env_step=0, call0=0, n_calls=1):
         z = torch.empty((n_calls, 3, self.n), dtype=torch.float64, device=self.device)
