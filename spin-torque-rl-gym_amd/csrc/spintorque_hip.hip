@@ -357,6 +357,7 @@ struct stg_ctx {
     int32_t hybrid = 1;                            // STG_HYBRID=0 switches the hybrid wave-specialised launch off (experiments)
     int32_t hybrid_min = 768;                      // fewest producer/consumer pairs for which the hybrid launch is used (STG_HYBRID_MIN)
     int32_t refill = -1, refill_check = STG_REFILL_CHECK_DEFAULT;        // STG_REFILL experiment override of cfg.lane_refill (-1: none)
+    int32_t refill_fair = 16;                      // STG_REFILL_FAIR: priority alternation of two refill queues per SIMD (bit of the 100 MHz clock; 0 off)
 };
 
 static int32_t walk_tiles_from_env() {
@@ -436,6 +437,7 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     if (const char* e = std::getenv("STG_HYBRID")) c->hybrid = std::atoi(e);
     if (const char* e = std::getenv("STG_HYBRID_MIN")) c->hybrid_min = std::atoi(e);
     if (const char* e = std::getenv("STG_SPREAD_MAX")) c->spread_max = std::atoi(e);
+    if (const char* e = std::getenv("STG_REFILL_FAIR")) c->refill_fair = std::atoi(e);
     if (const char* e = std::getenv("STG_REFILL")) {
         int r = 0, chk = 0;
         if (std::sscanf(e, "%d,%d", &r, &chk) >= 1) { c->refill = r; if (chk > 0) c->refill_check = chk; }
@@ -685,6 +687,9 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
             if ((int64_t)r * nw < nblk || nw > 0x7FFFFFFFll)
                 return fail(STG_E_INVALID, "lane refill: envs per lane x queues does not cover the batch");
             a.refill = r; a.refill_check = chk > 0 ? chk : STG_REFILL_CHECK_DEFAULT; a.refill_nw = (int32_t)nw;
+            // two queues per SIMD (more than 1024 queues): alternate their issue priority (stg_step_refill_kernel); STG_REFILL_FAIR=<bit>
+            // of the 100 MHz counter, 0 = off (experiments)
+            a.refill_fair = nw > 1024 ? ctx->refill_fair : 0;
             stg_dispatch_step_rk45_refill(a, ctx->cfg.thermal != 0, multi, ctx->axis_z_llgs, act_f64, st);
             HIP_TRY(hipGetLastError());
             return STG_OK;

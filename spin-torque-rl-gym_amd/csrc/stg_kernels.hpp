@@ -78,6 +78,8 @@ struct StepArgs {
     int32_t records;              // STG_OUT_RECORDS: `obs` is the record array [K or 1][N][STG_RECORD_BYTES], reward/term/trunc unused
     int32_t refill, refill_check; // lane-refill launch (stg_step_refill_kernel): envs per lane (rounds), attempts between refill points
     int32_t refill_nw;            // ... and its number of wavefronts (queues); refill * refill_nw >= ceil(N / 64)
+    int32_t refill_fair;          // refill launches with two queues per SIMD: bit of the 100 MHz real-time counter that alternates the two
+                                  // wavefronts' issue priority (0: off -- the SIMD then serves the older wavefront first, see the kernel)
     int32_t spread_max;           // sorted schedule, 4-wavefront workgroups: up to this many workgroups a workgroup takes ranks u, u+16, u+32,
                                   // u+48 of its tile (spread), beyond it four consecutive ranks (stg_slot_block)
     int32_t hybrid;               // wave-specialised launch of 1024 workgroups over more than 1024 blocks: number of producer/consumer pairs + 1
@@ -852,6 +854,7 @@ __global__ void __launch_bounds__(WGW * 64) stg_step_refill_kernel(const StepArg
 
     WaveProf prof;
     prof.start();
+    const int slot_parity = (int)(__builtin_amdgcn_s_getreg((4 << 11) | (0 << 6) | 4) & 1u);      // HW_ID wave slot (bits 3:0) of this SIMD
     take(lane, true);
     int q_next = 64;                                            // wave-uniform: the next queue entry to hand out
     const int q_len = R * 64;
@@ -859,6 +862,17 @@ __global__ void __launch_bounds__(WGW * 64) stg_step_refill_kernel(const StepArg
     for (;;) {
         // up to `check` attempts of the whole wavefront (lanes that are through walk along, frozen) ...
         for (int c = 0; c < check; ++c) {
+            // Two queues per SIMD (2048-queue launches): a SIMD serves its two wavefronts by priority, then AGE -- the older one issues
+            // whenever it can and runs at the speed of a lone wavefront, the younger one gets the leftover slots
+            // (tools/probes/simd_fairness.hip: two equal loops finish at 0.54 and 1.0 of the total), so the older queue drains at
+            // about half time and the younger then runs ALONE, at a lone wavefront's ~5 cycles per instruction instead of the ~4.2 two
+            // wavefronts reach together.  Equal queues should end together: every 8 attempts a wavefront takes its priority from a bit
+            // of the real-time counter -- a clock both wavefronts read, so they always hold opposite priorities -- XOR its wave-slot
+            // parity, and the favoured role alternates every 2^bit ticks of 10 ns.
+            if (a.refill_fair > 0 && (c & 7) == 0) {
+                const int ph = (int)((__builtin_amdgcn_s_memrealtime() >> a.refill_fair) & 1ull) ^ slot_parity;
+                if (ph) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+            }
             llgs_lane_gate(L, a.c.max_attempts);
             if (__ballot(L.active) == 0ull) break;
             V3 z2{0.0, 0.0, 0.0}, z3{0.0, 0.0, 0.0};
