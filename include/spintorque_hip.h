@@ -122,13 +122,14 @@ typedef struct {
                                        [N_global, 12] strided view of it (Gym's own orientation), no transposition or
                                        concatenation copy anywhere. */
     double noise_corr_time;         /* correlation_time of ThermalFluctuations (default 1e-12 s); used when noise_model = 1 */
-    int32_t lane_refill;            /* STG_SOLVER_RK45, single-step launches: every wavefront owns a queue of 64-env blocks of the sorted
-                                       schedule and a lane that has finished its env takes the next one while its neighbours keep
-                                       integrating (ABI v3).  0 = automatic (launches of more than 131072 envs: 1024 queues -- one refill
-                                       wavefront per SIMD -- up to 8 envs per lane, 2048 queues beyond), -1 = never, >= 2 = that many
-                                       envs per lane.  Per-env arithmetic is untouched: results are bit-identical to the
-                                       one-env-per-lane launch.  Not used with per-env parameter records, fused steps (K > 1) or a
-                                       forced wave_spec = 1. */
+    int32_t lane_refill;            /* STG_SOLVER_RK45, single-step launches: persistent wavefronts share one global queue of the launch's
+                                       envs in the sorted schedule's longest-first order, and a lane that has finished its env takes the next
+                                       entry while its neighbours keep integrating (ABI v3; the queue is global since round 4).  0 = automatic
+                                       (launches of more than 131072 envs, more than 81920 with the thermal field: 1024 wavefronts -- one per
+                                       SIMD -- up to 8 envs per lane on average, 2048 beyond), -1 = never, >= 2 = that many envs per lane on
+                                       average (ceil(blocks / lane_refill) wavefronts).  Per-env arithmetic is untouched: results are
+                                       bit-identical to the one-env-per-lane launch.  Not used with per-env parameter records, fused steps
+                                       (K > 1) or a forced wave_spec = 1. */
     int32_t reserved0;              /* must be 0 */
 } stg_config;
 
@@ -245,10 +246,12 @@ int stg_get_counters(stg_ctx* ctx, uint64_t* out, int32_t reset);
  *           wave-specialised pair, bit 31 = valid (a workgroup beyond the batch leaves 0)
  *   word 1, word 2: low 32 bits of the 100 MHz real-time counter (s_memrealtime) at the wavefront's start / when it retired (0: the
  *           wavefront had no env)
+ *   word 3: the wavefront's work -- the largest number of integrator work units (sub-steps / RK45 attempts) any of its lanes did in
+ *           this launch; 0 for a producer
  * Returns the number of WAVEFRONTS written or a negative error.  Synchronises the device.  Cost per launch: two s_getreg, two
- * s_memrealtime and three 4-byte stores per wavefront, nothing inside any loop.  The reference has no counterpart (its bookkeeping is
+ * s_memrealtime, a six-step lane reduction and four 4-byte stores per wavefront, nothing inside any loop.  The reference has no counterpart (its bookkeeping is
  * host-side: utils/monitoring.py:30-268). */
-#define STG_PLACEMENT_WORDS_PER_WAVE 3
+#define STG_PLACEMENT_WORDS_PER_WAVE 4
 int stg_get_placement(stg_ctx* ctx, int32_t launches_back, uint32_t* out, int32_t cap, int32_t* n_workgroups,
                       int32_t* waves_per_workgroup);
 

@@ -307,25 +307,23 @@ static int fail(int code, const std::string& msg) {
             return fail(STG_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
     } while (0)
 
-// automatic lane refill of the RK45 step (measured on 132 000 ... 1 048 576 envs): above 131 072 envs, with 1024
-// queues (one refill wavefront per SIMD; the 64-env blocks are dealt over them, so any batch size loads them evenly to within one
-// short block) while that leaves at most 8 envs per lane, else 2048 queues.  At exactly two envs per lane (131 072 envs) the refill
-// launch has nothing over the one-env-per-lane launch with its two wavefronts per SIMD; just above, that launch needs a third
-// round of workgroups and the refill launch does not (132 000 envs: 4.36 -> 3.38 ms).  Attempts between refill points: 64.
-constexpr int64_t STG_REFILL_AUTO_ENVS = 131073;
-constexpr int32_t STG_REFILL_CHECK_DEFAULT = 64;
-static inline void refill_auto(int64_t n, int& r, int64_t& nw) {
+// automatic lane refill of the RK45 step (stg_step_refill_kernel: persistent wavefronts sharing one global queue; measured on 81 921 ...
+// 1 048 576 envs, profiles/r04_refill_global_ab.txt): 1024 wavefronts -- one per SIMD -- while that leaves at most 8 envs per lane (up
+// to 524 288 envs), 2048 beyond.  From 131 073 envs at T = 0 K (up to there the one-env-per-lane launch with its two wavefronts per SIMD
+// is as fast: 131 072 envs 1.96 against 1.94 ms, 98 304 envs 1.81 against 1.87) and from 81 921 envs with the thermal field (just
+// above the hybrid wave-specialised launch; 86 016 ... 131 072 envs 3.03-3.20 -> 2.91-3.09 ms: there the launch is bound by its longest
+// env at the inline-normal loop's lone-wavefront speed either way).  Attempts between refill points: 32.
+constexpr int64_t STG_REFILL_AUTO_ENVS = 131073, STG_REFILL_AUTO_ENVS_THERMAL = 81921;
+constexpr int32_t STG_REFILL_CHECK_DEFAULT = 32;
+static inline void refill_auto(int64_t n, bool thermal, int& r, int64_t& nw) {
     r = 0; nw = 0;
-    static const int64_t min_envs = std::getenv("STG_REFILL_MIN") ? std::atoll(std::getenv("STG_REFILL_MIN")) : STG_REFILL_AUTO_ENVS;   // (experiments)
-    if (n < min_envs) return;
+    static const int64_t min_env = std::getenv("STG_REFILL_MIN") ? std::atoll(std::getenv("STG_REFILL_MIN")) : 0;   // (experiments)
+    if (n < (min_env > 0 ? min_env : (thermal ? STG_REFILL_AUTO_ENVS_THERMAL : STG_REFILL_AUTO_ENVS))) return;
     const int64_t nblk = ((n + TILE_ENVS - 1) / TILE_ENVS) * TILE_WAVES;      // blocks of whole tiles (a ragged tile's empty blocks included)
     nw = 1024;
     int64_t rr = (nblk + nw - 1) / nw;
     if (rr > 8) { nw = 2048; rr = (nblk + nw - 1) / nw; }
-    // (beyond 2048 x 1024 x 64 = 134 M envs -- they still fit the 288 GB part -- the queues get no longer, there are more of them: the
-    // contract of StepArgs is refill * refill_nw >= blocks, or envs would be left unstepped)
-    if (rr > 1024) { nw = (nblk + 1023) / 1024; rr = (nblk + nw - 1) / nw; }
-    r = (int)rr;
+    r = (int)(rr < 2 ? 2 : (rr > 0x7FFFFFFF ? 0x7FFFFFFF : rr));              // (envs per lane on average; only != 0 matters to the launch)
 }
 constexpr int32_t STG_WALK_TILES_DEFAULT = 1 << 20;   // all tiles of the group (fastest, see stg_slot_block)
 
@@ -340,6 +338,8 @@ struct stg_ctx {
     int32_t ncls = 0;
     const uint8_t* cls = nullptr;     // caller-owned device pointer
     unsigned long long* counters = nullptr;
+    unsigned long long* refill_cursor = nullptr;   // the refill launches' two alternating queue cursors (each in a 128-byte line of its own)
+    uint64_t refill_seq = 0;                       // refill launches so far: launch k uses cursor k & 1 and zeroes the other
     uint32_t* placement = nullptr;    // [PLACEMENT_RING][PLACEMENT_WORDS]: where the wavefronts of the last launches ran (stg_get_placement)
     uint64_t launch_seq = 0;          // step launches so far
     uint32_t* perm = nullptr;
@@ -357,7 +357,6 @@ struct stg_ctx {
     int32_t hybrid = 1;                            // STG_HYBRID=0 switches the hybrid wave-specialised launch off (experiments)
     int32_t hybrid_min = 768;                      // fewest producer/consumer pairs for which the hybrid launch is used (STG_HYBRID_MIN)
     int32_t refill = -1, refill_check = STG_REFILL_CHECK_DEFAULT;        // STG_REFILL experiment override of cfg.lane_refill (-1: none)
-    int32_t refill_fair = 16;                      // STG_REFILL_FAIR: priority alternation of two refill queues per SIMD (bit of the 100 MHz clock; 0 off)
 };
 
 static int32_t walk_tiles_from_env() {
@@ -437,7 +436,6 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     if (const char* e = std::getenv("STG_HYBRID")) c->hybrid = std::atoi(e);
     if (const char* e = std::getenv("STG_HYBRID_MIN")) c->hybrid_min = std::atoi(e);
     if (const char* e = std::getenv("STG_SPREAD_MAX")) c->spread_max = std::atoi(e);
-    if (const char* e = std::getenv("STG_REFILL_FAIR")) c->refill_fair = std::atoi(e);
     if (const char* e = std::getenv("STG_REFILL")) {
         int r = 0, chk = 0;
         if (std::sscanf(e, "%d,%d", &r, &chk) >= 1) { c->refill = r; if (chk > 0) c->refill_check = chk; }
@@ -447,7 +445,7 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     const size_t N = (size_t)n_envs;
     const size_t rs = al(N * sizeof(EnvRec)), r4 = al(N * 4), ra = al(N * 16);
     const size_t rp = al(sizeof(uint32_t) * PLACEMENT_RING * PLACEMENT_WORDS);
-    const size_t total = rs + r4 + ra + rp + al(sizeof(double) * STG_MAX_CLASSES * C_COUNT) +
+    const size_t total = rs + r4 + ra + rp + 256 + al(sizeof(double) * STG_MAX_CLASSES * C_COUNT) +
                          COUNTER_STRIPES * COUNTER_STRIDE * sizeof(unsigned long long);
     hipError_t e = hipMalloc(&c->slab, total);
     if (e != hipSuccess) { delete c; return fail(STG_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
@@ -460,6 +458,7 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     c->perm = (uint32_t*)p; p += r4;
     c->act_sorted = (void*)p; p += ra;
     c->placement = (uint32_t*)p; p += rp;
+    c->refill_cursor = (unsigned long long*)p; p += 256;
     *out = c;
     return STG_OK;
 }
@@ -679,17 +678,18 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
         const int64_t nblk = ((ctx->N + TILE_ENVS - 1) / TILE_ENVS) * TILE_WAVES;
         int r = 0, chk = STG_REFILL_CHECK_DEFAULT;
         int64_t nw = 0;
-        if (ctx->cfg.lane_refill == 0) refill_auto(ctx->N, r, nw);
+        if (ctx->cfg.lane_refill == 0) refill_auto(ctx->N, ctx->cfg.thermal != 0, r, nw);
         else if (ctx->cfg.lane_refill > 0) { r = ctx->cfg.lane_refill; nw = (nblk + r - 1) / r; }
         if (ctx->refill >= 0) { r = ctx->refill; chk = ctx->refill_check; nw = r >= 2 ? (nblk + r - 1) / r : 0; }
         // (not combined with the wave-specialised launch: a forced wave_spec = 1 keeps the one-env-per-lane kernel)
-        if (r >= 2 && !(ctx->cfg.thermal && ctx->cfg.wave_spec > 0)) {
-            if ((int64_t)r * nw < nblk || nw > 0x7FFFFFFFll)
-                return fail(STG_E_INVALID, "lane refill: envs per lane x queues does not cover the batch");
+        if (r >= 2 && nw >= 1 && !(ctx->cfg.thermal && ctx->cfg.wave_spec > 0)) {
+            if (nw > 0x7FFFFFFFll) return fail(STG_E_INVALID, "lane refill: too many wavefronts");
             a.refill = r; a.refill_check = chk > 0 ? chk : STG_REFILL_CHECK_DEFAULT; a.refill_nw = (int32_t)nw;
-            // two queues per SIMD (more than 1024 queues): alternate their issue priority (stg_step_refill_kernel); STG_REFILL_FAIR=<bit>
-            // of the 100 MHz counter, 0 = off (experiments)
-            a.refill_fair = nw > 1024 ? ctx->refill_fair : 0;
+            // two cursors alternate: this launch finds its own at 0 (zeroed by the previous refill launch, or by stg_create) and
+            // zeroes the next one's -- launches of a context are ordered on their stream
+            a.refill_cursor = ctx->refill_cursor + (ctx->refill_seq & 1) * 16;
+            a.refill_cursor_next = ctx->refill_cursor + ((ctx->refill_seq + 1) & 1) * 16;
+            ctx->refill_seq += 1;
             stg_dispatch_step_rk45_refill(a, ctx->cfg.thermal != 0, multi, ctx->axis_z_llgs, act_f64, st);
             HIP_TRY(hipGetLastError());
             return STG_OK;

@@ -76,10 +76,10 @@ struct StepArgs {
     int32_t K, out_every, autoreset;
     int32_t walk;                 // tiles of an XCD group in flight together (sorted schedule, see stg_slot_block)
     int32_t records;              // STG_OUT_RECORDS: `obs` is the record array [K or 1][N][STG_RECORD_BYTES], reward/term/trunc unused
-    int32_t refill, refill_check; // lane-refill launch (stg_step_refill_kernel): envs per lane (rounds), attempts between refill points
-    int32_t refill_nw;            // ... and its number of wavefronts (queues); refill * refill_nw >= ceil(N / 64)
-    int32_t refill_fair;          // refill launches with two queues per SIMD: bit of the 100 MHz real-time counter that alternates the two
-                                  // wavefronts' issue priority (0: off -- the SIMD then serves the older wavefront first, see the kernel)
+    int32_t refill, refill_check; // lane-refill launch (stg_step_refill_kernel): != 0 selects it; attempts between refill points
+    int32_t refill_nw;            // ... and its number of (persistent) wavefronts
+    unsigned long long* refill_cursor;   // ... the cursor of its global queue (0 when the launch starts)
+    unsigned long long* refill_cursor_next;   // ... and the cursor of the NEXT refill launch, which this launch zeroes (two cursors alternate)
     int32_t spread_max;           // sorted schedule, 4-wavefront workgroups: up to this many workgroups a workgroup takes ranks u, u+16, u+32,
                                   // u+48 of its tile (spread), beyond it four consecutive ranks (stg_slot_block)
     int32_t hybrid;               // wave-specialised launch of 1024 workgroups over more than 1024 blocks: number of producer/consumer pairs + 1
@@ -329,8 +329,10 @@ __device__ __forceinline__ void write_record_obs(void* base, int64_t i, const V3
 //         wavefront of a wave-specialised pair, bit 31 valid
 //     [1], [2] the low 32 bits of the 100 MHz real-time counter (s_memrealtime) when the wavefront started / retired (0: it had no
 //         env): with [0] the per-SIMD timeline of the launch -- who ran where, next to whom, for how long
+//     [3] the wavefront's work: the largest number of integrator work units (RK4 / Euler sub-steps, RK45 attempts) any of its lanes
+//         did in this launch (a refill wavefront: the largest per-lane total over its queue); 0 for a producer
 constexpr int PLACEMENT_CAP = 4096;
-constexpr int PLACEMENT_ENTRY = 3;
+constexpr int PLACEMENT_ENTRY = 4;
 constexpr int PLACEMENT_WORDS = 2 + PLACEMENT_ENTRY * PLACEMENT_CAP;
 constexpr int PLACEMENT_RING = 32;        // tables kept: one per launch, the last PLACEMENT_RING launches
 __device__ __forceinline__ void record_placement(uint32_t* table, int wave, int lane, bool producer) {
@@ -344,13 +346,20 @@ __device__ __forceinline__ void record_placement(uint32_t* table, int wave, int 
     e[0] = (hw & 0xFFFFu) | ((xcc & 0xFu) << 16) | (producer ? (1u << 20) : 0u) | (1u << 31);
     e[1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
     e[2] = 0u;
+    e[3] = 0u;
 }
-// ... and when the wavefront retires (every exit of a wavefront that had work)
-__device__ __forceinline__ void record_retired(uint32_t* table, int wave, int lane) {
-    if (table == nullptr || lane != 0) return;
+// ... and when the wavefront retires (every exit of a wavefront that had work); `work`: this lane's integrator work units
+__device__ __forceinline__ void record_retired(uint32_t* table, int wave, int lane, unsigned long long work) {
+    if (table == nullptr) return;
+    uint32_t w = work > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)work;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)w, o); w = v > w ? v : w; }
+    if (lane != 0) return;
     const uint32_t wpw = blockDim.x >> 6, idx = blockIdx.x * wpw + (uint32_t)wave;
     if (idx >= (uint32_t)PLACEMENT_CAP) return;
-    table[2 + PLACEMENT_ENTRY * idx + 2] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    uint32_t* e = table + 2 + PLACEMENT_ENTRY * idx;
+    e[2] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    e[3] = w;
 }
 
 constexpr int COUNTER_STRIPES = 1024;     // copies of the on-device counters (one 64-byte line each)
@@ -687,7 +696,7 @@ stg_step_kernel(const StepArgs a) {
             const RngKey rk{a.c.seed, env_id, s_rng[cw * 64 + lane]};
             produce_normals<NT, FIELD, DEPTH, BARRIER>(s_norm, s_hs, lane, rk, n_first, n_chunk, ghs);
         }
-        record_retired(a.placement, wave, lane);
+        record_retired(a.placement, wave, lane, 0ull);
         return;
     }
 
@@ -742,7 +751,7 @@ stg_step_kernel(const StepArgs a) {
         env_step_tail(a, i, ko, wr, live, lane_solves, row, env_id, m, tgt, etot, step, rng, done, J, T, so, c_steps, c_sub, c_noop);
     }
     if (live) store_state(a.s, i, m, tgt, etot, step, rng, done);
-    record_retired(a.placement, wave, lane);
+    record_retired(a.placement, wave, lane, c_sub);
     // on-device metrics (the reference's EnvironmentMonitor/solver stats are host-side bookkeeping): one atomic per
     // counter per wavefront, into one of COUNTER_STRIPES copies
     const int ci = PC ? wave : cw;                                  // (this wavefront's counter triple)
@@ -753,19 +762,26 @@ stg_step_kernel(const StepArgs a) {
 // env.step with LANE REFILL (RK45, one env-step per launch): throughput launches with several envs per lane
 // ------------------------------------------------------------------------------------------------
 // In stg_step_kernel a lane integrates ONE env and then idles until the slowest lane of its wavefront is through: after the
-// duration sort the lanes of a wavefront still differ in attempts (mean/max 0.81: attempts per picosecond vary 1.0-1.9 with
-// nothing known before the solve), and the issue slots of an idle lane are paid all the same.  Here a wavefront owns a QUEUE
-// of R x 64 envs -- R blocks of 64 slots of the sorted schedule -- and a lane that has finished its env writes that env's
-// outputs and takes the next queue entry while its neighbours keep integrating; per-env arithmetic is exactly that of
-// stg_step_kernel (llgs_lane_begin / _attempt / _finish, env_step_tail), so results are bit-identical (tested).
-//  * Queue of wavefront w (of nw = ceil(blocks / R)): round r takes block r * nw + (r odd ? nw - 1 - w : w) of the
-//    rank-major order over the tiles (all tiles' longest block first, ...): boustrophedon, so every wavefront gets the same
-//    total work to within the spread of one block, and inside a wavefront the queue runs from long to short envs (a short
-//    tail at the end).
-//  * A refill point -- finish the env (reload its record, tail of the env-step, stores), take the next entry (state load,
-//    action, the solve's prologue: two RHS calls, initial step) -- is lane-divergent code that the whole wavefront waits
-//    for; it is entered at most every `refill_check` attempts (lanes that finished within that window go together) or when
-//    no lane is integrating.
+// duration sort the lanes of a wavefront still differ in attempts (attempts per picosecond vary 1.0-1.9 with nothing known
+// before the solve: the mean lane of a 64-env block does 0.5-0.7 of the attempts of its slowest lane), and the issue slots of an
+// idle lane are paid all the same.  Here nw PERSISTENT wavefronts (one or two per SIMD) share ONE GLOBAL QUEUE of all the launch's
+// envs in the rank-major order of the sorted schedule (every tile's longest block first, ...): a wavefront starts with block w of that
+// order, and a lane that has finished its env writes that env's outputs and takes the next entry of the queue while its neighbours
+// keep integrating.  Longest envs first, handed to whichever lane ANYWHERE on the chip runs dry first: the longest-processing-time
+// rule at lane granularity -- the launch ends with the shortest envs, every SIMD retires within one short env of the others
+// (round 4, profiles/r04_refill_global_ab.txt; rounds 2-3 gave every wavefront a fixed queue of R blocks: a lane that finished early
+// got only what its own wavefront's queue held -- 196 608 envs 4.40 -> 3.67 ms, 262 144 envs 5.18 -> 4.49 ms).  Per-env arithmetic
+// is exactly that of stg_step_kernel (llgs_lane_begin / _attempt / _finish, env_step_tail), and an env's arithmetic never depends on
+// the lane that runs it, so results are bit-identical whatever the order the entries are taken in (tested).
+//  * Queue entry p = slot p % 64 of block p / 64 of the rank-major order; entries [0, nw * 64) are the initial envs, the rest goes
+//    through the cursor: ONE atomic per wavefront and refill point (the wavefront's takers get consecutive entries).  Two cursors
+//    alternate between launches: a launch finds its own at 0 and zeroes the next one's (no memset between launches).
+//  * A refill point -- finish the env (tail of the env-step, stores), take the next entry (state load, action, the solve's
+//    prologue: two RHS calls, initial step) -- is ~2700 instructions of lane-divergent code that the whole wavefront waits for; it
+//    is entered at most every `refill_check` attempts (lanes that finished within that window go together) or when no lane is
+//    integrating.  A lane that draws an empty slot (a ragged tile's slots beyond N sit among the others) draws again next time.
+//  * Two wavefronts per SIMD: the SIMD serves the older one first (arbitration is by priority, then age:
+//    tools/probes/simd_fairness.hip), which with a shared queue only means that it takes more entries.
 template <bool THERMAL, bool MULTI, bool AXIS_Z, typename AT, int WGW>
 __global__ void __launch_bounds__(WGW * 64) stg_step_refill_kernel(const StepArgs a) {
     extern __shared__ double s_tab[];
@@ -777,10 +793,10 @@ __global__ void __launch_bounds__(WGW * 64) stg_step_refill_kernel(const StepArg
         __syncthreads();
     }
     const int64_t N = a.N;
-    const int R = a.refill;
     const int64_t tiles = (N + TILE_ENVS - 1) / TILE_ENVS, nblk = tiles * TILE_WAVES, nw = a.refill_nw;   // (blocks of whole tiles)
     const int64_t w = (int64_t)blockIdx.x * WGW + wave;
     record_placement(a.placement, wave, lane, false);
+    if (w == 0 && lane == 0) *a.refill_cursor_next = 0ull;      // (the next refill launch's cursor: nobody reads it during this launch)
     if (w >= nw) return;
     const AT* act = (const AT*)a.actions;
     const Recorder norec{};
@@ -807,10 +823,9 @@ __global__ void __launch_bounds__(WGW * 64) stg_step_refill_kernel(const StepArg
     V3 out_m{0.0, 0.0, 1.0};
 
     // takes queue entry p (if there is one): state, action, the solve's prologue
-    auto take = [&](int p, bool want) {
-        const int r = p >> 6;
-        const int64_t idx = (int64_t)r * nw + ((r & 1) ? (nw - 1 - w) : w);
-        const bool valid_blk = want && r < R && idx < nblk;
+    auto take = [&](int64_t p, bool want) {
+        const int64_t idx = p >> 6;                              // block of the rank-major order
+        const bool valid_blk = want && idx < nblk;
         const int64_t slot = (valid_blk ? refill_slot_base(idx, tiles) : 0) + (p & 63);
         const bool valid = valid_blk && slot < N;
         if (!valid) return;
@@ -854,45 +869,39 @@ __global__ void __launch_bounds__(WGW * 64) stg_step_refill_kernel(const StepArg
 
     WaveProf prof;
     prof.start();
-    const int slot_parity = (int)(__builtin_amdgcn_s_getreg((4 << 11) | (0 << 6) | 4) & 1u);      // HW_ID wave slot (bits 3:0) of this SIMD
-    take(lane, true);
-    int q_next = 64;                                            // wave-uniform: the next queue entry to hand out
-    const int q_len = R * 64;
+    take(w * 64 + lane, true);
+    const int64_t g_first = nw * 64, g_total = nblk * 64;       // positions [g_first, g_total) go through the cursor
+    bool more = g_first < g_total;                              // wave-uniform: the queue may still hold entries
     const int check = a.refill_check > 0 ? a.refill_check : 1;
     for (;;) {
         // up to `check` attempts of the whole wavefront (lanes that are through walk along, frozen) ...
         for (int c = 0; c < check; ++c) {
-            // Two queues per SIMD (2048-queue launches): a SIMD serves its two wavefronts by priority, then AGE -- the older one issues
-            // whenever it can and runs at the speed of a lone wavefront, the younger one gets the leftover slots
-            // (tools/probes/simd_fairness.hip: two equal loops finish at 0.54 and 1.0 of the total), so the older queue drains at
-            // about half time and the younger then runs ALONE, at a lone wavefront's ~5 cycles per instruction instead of the ~4.2 two
-            // wavefronts reach together.  Equal queues should end together: every 8 attempts a wavefront takes its priority from a bit
-            // of the real-time counter -- a clock both wavefronts read, so they always hold opposite priorities -- XOR its wave-slot
-            // parity, and the favoured role alternates every 2^bit ticks of 10 ns.
-            if (a.refill_fair > 0 && (c & 7) == 0) {
-                const int ph = (int)((__builtin_amdgcn_s_memrealtime() >> a.refill_fair) & 1ull) ^ slot_parity;
-                if (ph) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-            }
             llgs_lane_gate(L, a.c.max_attempts);
             if (__ballot(L.active) == 0ull) break;
             V3 z2{0.0, 0.0, 0.0}, z3{0.0, 0.0, 0.0};
             llgs_lane_attempt<THERMAL, false, AXIS_Z>(L, out_m, k, tb, a.c.rtol, a.c.atol, a.c.max_step, norec, noek, ns, z2, z3);
         }
         // ... then a refill point: finished lanes write their env; every lane without an env -- finished just now, or one that drew an
-        // entry beyond N earlier (the ragged last block sits at the FRONT of the queue) -- takes entries q_next, q_next + 1, ... in lane order
+        // empty slot earlier -- takes the next entries of the global queue, in lane order
         const bool fin = has_env && !L.active;
-        const bool more = q_next < q_len;
         if (__ballot(fin) != 0ull || (more && __ballot(!has_env) != 0ull)) {
             if (fin) finish();
             const unsigned long long takers = __ballot(!has_env);
-            const int rank = (int)__builtin_popcountll(takers & ((1ull << lane) - 1ull));
-            take(q_next + rank, !has_env && q_next + rank < q_len);
-            q_next += (int)__builtin_popcountll(takers);
+            if (more && takers != 0ull) {
+                const int n_take = (int)__builtin_popcountll(takers), first = (int)__builtin_ctzll(takers);
+                const int rank = (int)__builtin_popcountll(takers & ((1ull << lane) - 1ull));
+                unsigned long long base = 0;
+                if (lane == first) base = atomicAdd(a.refill_cursor, (unsigned long long)n_take);
+                base = (unsigned long long)__shfl((long long)base, first);
+                const int64_t g0 = g_first + (int64_t)base;
+                take(g0 + rank, !has_env && g0 + rank < g_total);
+                more = g0 + n_take < g_total;
+            }
         }
-        if (__ballot(has_env) == 0ull && q_next >= q_len) break;
+        if (__ballot(has_env) == 0ull && !more) break;
     }
     prof.stop(L.attempts);
-    record_retired(a.placement, wave, lane);
+    record_retired(a.placement, wave, lane, c_sub);
     wave_add3(a.counters + (size_t)((blockIdx.x * WGW + wave) % COUNTER_STRIPES) * COUNTER_STRIDE, s_cnt + wave * 3, c_steps, c_sub, c_noop);
 }
 

@@ -41,8 +41,8 @@ class EnvConfig:
     correlation_time: float = 1e-12           # ThermalFluctuations.correlation_time, for noise_model='ou'
     out_layout: str = "soa"                   # 'soa': obs [12,N] + reward/terminated/truncated arrays; 'records': one
                                               # [N,56]-byte record array (what the multi-GPU gather moves, copy-free)
-    lane_refill: Optional[int] = None         # RK45 throughput launches: envs per lane of the lane-refill kernel; None = automatic
-                                              # (launches of more than 131 072 envs: include/spintorque_hip.h, cfg.lane_refill),
+    lane_refill: Optional[int] = None         # RK45 throughput launches: envs per lane (on average) of the lane-refill kernel; None =
+                                              # automatic (the thresholds are in include/spintorque_hip.h, cfg.lane_refill),
                                               # False/0 = never, n >= 2 = force (results are bit-identical)
     diagnostics: bool = False                 # also write the step's fp64 reward, per-step energy and status bytes into separate
                                               # arrays (the C-ABI's optional outputs).  Off: those pointers are NULL, a step writes the
@@ -385,7 +385,7 @@ class HipBackend:
         return {"env_steps": int(out[0]), "work_units": int(out[1]), "noop_steps": int(out[3])}
 
     PLACEMENT_CAP = 4096
-    PLACEMENT_ENTRY = 3                   # STG_PLACEMENT_WORDS_PER_WAVE
+    PLACEMENT_ENTRY = 4                   # STG_PLACEMENT_WORDS_PER_WAVE
 
     def placement(self, launches_back=0, raw=False):
         """Where the dispatcher put the wavefronts of a recent step launch and when each ran (stg_get_placement; 0 = the latest, up to
@@ -396,7 +396,7 @@ class HipBackend:
         launch the time of its two wavefronts back to back.  From the start / retire times: `span_us` = first start to last retire;
         `simd_busy_frac` = mean over the 1024 SIMDs of the share of that span during which the SIMD held at least one integrating
         wavefront; `last_simd_alone_frac` = share of the span left once 90 % of the SIMDs in use have retired their last integrating
-        wavefront (the tail a makespan-bound launch ends with).  raw=True adds the arrays (`where`, `producer`, `t0_us`, `t1_us` per recorded wavefront).
+        wavefront (the tail a makespan-bound launch ends with).  raw=True adds the arrays (`where`, `producer`, `t0_us`, `t1_us`, `work`, `slot` per recorded wavefront).
         Synchronises the device."""
         words = self.PLACEMENT_CAP * self.PLACEMENT_ENTRY
         out = (C.c_uint32 * words)()
@@ -445,7 +445,7 @@ class HipBackend:
             t90 = float(ends[max(int(0.9 * len(ends)) - 1, 0)])
             res["last_simd_alone_frac"] = round(max(0.0, float(ends[-1]) - t90) / span, 4) if span > 0 else None
             if raw:
-                res.update(where=where, producer=prod, t0_us=s0, t1_us=s1)
+                res.update(where=where, producer=prod, t0_us=s0, t1_us=s1, work=e[:, 3].astype(np.int64), slot=(w & 0xF).astype(np.int64))
         return res
 
     def thermal_normals(self, env_step=0, call0=0, n_calls=1):

@@ -40,7 +40,7 @@ def run(name, n, solver, thermal, mixed=False, tm="reference", steps=4):
         b.step(acts[k], autoreset=True)
     torch.cuda.synchronize()
     p = b.placement(0, raw=True)
-    where, prod, t0, t1 = p["where"], p["producer"], p["t0_us"], p["t1_us"]
+    where, prod, t0, t1, work, slot = p["where"], p["producer"], p["t0_us"], p["t1_us"], p["work"], p["slot"]
     sel = (~prod) & (t1 > 0)
     dur = t1 - t0
     print(f"== {name}: {n} envs {solver} thermal={thermal} {'mixed ' + tm if mixed else ''}: {p['workgroups']} workgroups x {p['waves_per_workgroup']} "
@@ -55,11 +55,14 @@ def run(name, n, solver, thermal, mixed=False, tm="reference", steps=4):
           f"per-SIMD last retire: min {last_end.min():.1f} median {np.median(last_end):.1f} max {last_end.max():.1f} us")
     print(f"   wavefront durations: min {dur[sel].min():.1f} median {np.median(dur[sel]):.1f} max {dur[sel].max():.1f} us; starts after launch: "
           f"median {np.median(t0[sel] - start0):.1f} max {(t0[sel] - start0).max():.1f} us")
-    for k in keys[np.argsort(-last_end)[:4]]:
+    us_per_unit = dur[sel] / np.maximum(work[sel], 1)
+    print(f"   us per work unit of a wavefront: min {us_per_unit.min():.3f} median {np.median(us_per_unit):.3f} max {us_per_unit.max():.3f}")
+    order = np.argsort(-last_end)
+    for k in list(keys[order[:3]]) + list(keys[order[-2:]]):
         m = sel & (where == k)
-        iv = sorted(zip((t0[m] - start0).round(1), (t1[m] - start0).round(1)))
+        iv = sorted(zip((t0[m] - start0).round(1).tolist(), (t1[m] - start0).round(1).tolist(), work[m].tolist(), slot[m].tolist()))
         co = prod & (where == k)
-        print(f"   SIMD {int(k):#x} retires last at {float(max(b_ for _, b_ in iv)):.1f} us: integrating {iv}"
+        print(f"   SIMD {int(k):#x} retires last at {float(max(b_ for _, b_, _, _ in iv)):.1f} us: integrating (start, retire, work units, wave slot) {iv}"
               + (f", producers {sorted(zip((t0[co] - start0).round(1), (t1[co] - start0).round(1)))}" if co.any() else ""))
     env.close()
 
