@@ -229,6 +229,35 @@ __global__ void __launch_bounds__(PLAN_THREADS) stg_plan_tile_kernel(const PlanA
     // workgroups) 131 072 envs 0.557 against 0.745 ms.
     __shared__ int grp_d[TILE_WAVES / 4];
     __shared__ uint8_t grp_rank[TILE_WAVES / 4];
+    // Kind-pure groups (regroup >= 2).  A kind's ramp rarely ends on a group boundary (256 slots), so one group per boundary held the
+    // SHORT end of one kind's ramp and the LONG start of the next: a 4-wavefront workgroup whose wavefronts run 150 ... 1000 sub-steps
+    // keeps its CU slot until the longest is through.  Each kind therefore keeps a whole number of groups of its longest envs in
+    // place and hands its remainder (< 256 slots, its SHORTEST envs) to a common tail behind all kinds: every group but the (at most
+    // three) tail groups is of one kind and one duration, and the tail groups are short throughout.
+    __shared__ uint32_t k_start[3], k_main[3], k_main_off[3], k_tail_off[3];
+    const bool kind_pure = a.by_kind && a.regroup >= 2;
+    if (kind_pure) {
+        if (tid == 0) {
+            uint32_t main_off = 0, tail_tot = 0, cnt_k[3];
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t s0 = start[k * PLAN_DUR] - cnt[k * PLAN_DUR], e0 = start[(k + 1) * PLAN_DUR - 1];
+                k_start[k] = s0; cnt_k[k] = e0 - s0;
+                k_main[k] = cnt_k[k] & ~255u;
+                k_main_off[k] = main_off; main_off += k_main[k];
+            }
+            for (int k = 0; k < 3; ++k) { k_tail_off[k] = main_off + tail_tot; tail_tot += cnt_k[k] - k_main[k]; }
+        }
+        __syncthreads();
+    }
+    auto slot_of = [&](int r) -> uint32_t {
+        uint32_t sl = (start[key[r]] - cnt[key[r]]) + rank[r];                                     // exclusive start of the bucket + rank in it
+        if (kind_pure) {
+            const int k = key[r] / PLAN_DUR;
+            const uint32_t pos = sl - k_start[k];
+            sl = pos < k_main[k] ? k_main_off[k] + pos : k_tail_off[k] + (pos - k_main[k]);
+        }
+        return sl;
+    };
     if (a.by_kind && a.regroup) {
         constexpr int NG = TILE_WAVES / 4;
         if (tid < NG) grp_d[tid] = 0x7fffffff;                 // (groups beyond N: last)
@@ -236,8 +265,16 @@ __global__ void __launch_bounds__(PLAN_THREADS) stg_plan_tile_kernel(const PlanA
 #pragma unroll
         for (int r = 0; r < PLAN_ITEMS; ++r)
             if (key[r] >= 0) {
-                const uint32_t sl = (start[key[r]] - cnt[key[r]]) + rank[r];
-                if ((sl & 255u) == 0u) grp_d[sl >> 8] = key[r] % PLAN_DUR;
+                const uint32_t sl = slot_of(r);
+                // regroup 1: by the pulse duration of the group's first env; 2 / 3: by the group's LONGEST block (a group that straddles the
+                // boundary between two kinds holds the short end of one ramp and the long start of the next: keyed by its first env it sorts
+                // last and its long block then runs at the very end) -- 2: estimated cost = duration x the kind's cost of a sub-step (measured
+                // on homogeneous batches, profiles/r03_devphys_regroup.txt: STT 0.466, SOT 0.646, VCMA 0.419 ms per step -> 32 : 44 : 29),
+                // 3: duration
+                const int dq = key[r] % PLAN_DUR, kind = key[r] / PLAN_DUR;
+                const int f = kind == 1 ? 44 : (kind == 2 ? 29 : 32);
+                if (a.regroup == 1) { if ((sl & 255u) == 0u) grp_d[sl >> 8] = dq; }
+                else if ((sl & 63u) == 0u) atomicMin(&grp_d[sl >> 8], a.regroup == 2 ? (1 << 20) - (PLAN_DUR - dq) * f : dq);
             }
         __syncthreads();
         // (a ragged tile's last, partly filled group keeps its place behind the full ones: the step kernel's "slot < N" test relies on
@@ -257,7 +294,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) stg_plan_tile_kernel(const PlanA
     for (int r = 0; r < PLAN_ITEMS; ++r) {
         const int64_t i = base + r * PLAN_THREADS + tid;
         if (key[r] >= 0) {
-            uint32_t sl = (start[key[r]] - cnt[key[r]]) + rank[r];                                 // exclusive start
+            uint32_t sl = slot_of(r);
             if (a.by_kind && a.regroup) sl = ((uint32_t)grp_rank[sl >> 8] << 8) | (sl & 255u);
             const int64_t slot = base + sl;
             a.perm[slot] = (uint32_t)i;
@@ -366,6 +403,8 @@ static int32_t walk_tiles_from_env() {
     int32_t w = v > 0 ? v : STG_WALK_TILES_DEFAULT;
     const char* sn = std::getenv("STG_SNAKE");       // unset: automatic (see stg_slot_block)
     if (sn) w |= (int32_t)(std::atoi(sn) != 0 ? STG_WALK_SNAKE_ON : STG_WALK_SNAKE_OFF);
+    // STG_SNAKE_ROUNDS=<n> (with STG_SNAKE=1): the boustrophedon applies to the first n rounds only (0 = every round)
+    if (const char* sr = std::getenv("STG_SNAKE_ROUNDS")) w |= (int32_t)(((unsigned)std::atoi(sr) & 0xFFu) << STG_WALK_ROUNDS_SHIFT);
     return w;
 }
 
@@ -641,7 +680,12 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
         pa.env_type = ctx->per_env ? ctx->env_type : nullptr;
         pa.by_kind = (ctx->cfg.torque_model == 1 && ((ctx->ncls > 1 && ctx->cls) || ctx->per_env)) ? 1 : 0;
         // (measured range, tools/devphys_ab.py: 4-wavefront workgroups, between one and a half and two workgroups per CU)
-        pa.regroup = (!ctx->per_env && ctx->N >= 98304 && ctx->N <= 131072 && !getenv("STG_NO_REGROUP")) ? 1 : 0;
+        // device-physics model with a class table: kind-pure groups of four blocks (= whole workgroups of the step launch), dealt by the
+        // estimated cost of their longest block (round 4, profiles/r04_devphys_order_ab.txt: 1.08-1.37x at 98 304 ... 1 048 576 envs;
+        // rounds 2-3 keyed the groups by their first env and only at 98 304 ... 131 072 envs).  Per-env parameter records launch
+        // one-wavefront workgroups: no groups there.  STG_REGROUP=0/1/2/3 forces a mode (experiments).
+        pa.regroup = (pa.by_kind && !ctx->per_env) ? 2 : 0;
+        if (const char* rg = std::getenv("STG_REGROUP")) pa.regroup = std::atoi(rg);
         const dim3 g((unsigned)((ctx->N + TILE_ENVS - 1) / TILE_ENVS));
         hipLaunchKernelGGL(stg_plan_tile_kernel, g, dim3(PLAN_THREADS), 0, st, pa);
         a.perm = ctx->perm;
