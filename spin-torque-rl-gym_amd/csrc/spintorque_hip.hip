@@ -698,9 +698,9 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
     a.obs = obs; a.final_obs = final_obs; a.reward = reward; a.reward64 = reward_f64; a.energy = energy; a.term = terminated; a.trunc = truncated; a.status = status;
     // the Simple solver only draws a thermal field when temperature > 0 (simple_solver.py:321,378)
     const bool thermal = ctx->cfg.thermal && ctx->cfg.temperature > 0;
-    const bool multi = ctx->ncls > 1 || ctx->per_env;
+    const int multi = ctx->per_env ? 2 : (ctx->ncls > 1 ? 1 : 0);      // (2: every lane derives its constants from its env's record, in registers)
     const bool devphys = ctx->cfg.torque_model == 1;
-    a.force_wg1 = ctx->per_env ? 1 : 0;       // per-env rows fill the 64-row LDS block: 64 integrating lanes per workgroup
+    a.force_wg1 = 0;
     // wave_spec: 0 = automatic (thermal launches of at most STG_WAVE_SPEC_MAX_ENVS envs, i.e. latency-bound ones),
     // 1 = always, -1 = never.  Results do not depend on it.
     bool pc = ctx->cfg.wave_spec > 0 || (ctx->cfg.wave_spec == 0 && ctx->N <= STG_WAVE_SPEC_MAX_ENVS);
@@ -734,7 +734,7 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
             a.refill_cursor = ctx->refill_cursor + (ctx->refill_seq & 1) * 16;
             a.refill_cursor_next = ctx->refill_cursor + ((ctx->refill_seq + 1) & 1) * 16;
             ctx->refill_seq += 1;
-            stg_dispatch_step_rk45_refill(a, ctx->cfg.thermal != 0, multi, ctx->axis_z_llgs, act_f64, st);
+            stg_dispatch_step_rk45_refill(a, ctx->cfg.thermal != 0, multi != 0, ctx->axis_z_llgs, act_f64, st);
             HIP_TRY(hipGetLastError());
             return STG_OK;
         }

@@ -620,7 +620,12 @@ __device__ __forceinline__ void env_step_tail(const StepArgs& a, int64_t i, int6
 // every SIMD one integrating and one producing wavefront at 65 536 envs (tools/probes/wave_placement.hip).  (A 4 + 4
 // form -- producer 4+w serving integrating wavefront 3-w, all eight in lockstep -- was built and measured: no better
 // for RK45, 8 % worse for RK4; it is gone.)
-template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, bool DEVPHYS, typename AT, bool PC, int WGW>
+// MULTI: 0 = one device class (constants through scalar loads), 1 = class table staged in LDS, 2 = per-env parameter records: every lane
+// derives its constants from its env's record straight into REGISTERS (a private array with compile-time indices only: the constants a
+// kernel never reads cost nothing).  Rounds 2-3 derived them into a 64-row LDS block -- 23.5 KB per 64-lane workgroup, which held a CU
+// to six wavefronts (1.5 per SIMD) and forced one-wavefront workgroups, which the dispatcher spreads unevenly (1 ... 6 per SIMD): the
+// per-env cfg4 row ran at a SIMD busy share of 0.78 (profiles/r04_simd_timeline.txt).
+template <int SOLVER, bool THERMAL, int MULTI, bool AXIS_Z, bool DEVPHYS, typename AT, bool PC, int WGW>
 #ifndef STG_STEP_ATTR
 #define STG_STEP_ATTR
 #endif
@@ -629,7 +634,7 @@ template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, bool DEVPHYS, typen
 // register decides between three and four resident wavefronts per SIMD, so they are held to four: 127 VGPRs, no spills (cfg4 class
 // table 0.516 -> 0.505 ms, RK4 at T = 0 K 262 144 envs 0.513 -> 0.497 ms).  Not the class-table kernel with 64-thread workgroups (per-env
 // parameter records: its 23.5 KB LDS block per workgroup bounds the occupancy anyway, and the tighter allocation cost it 6 %).)
-__global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64, (SOLVER != STG_SOLVER_RK45 && !THERMAL && !DEVPHYS && AXIS_Z && !(MULTI && WGW == 1)) ? 4 : 1) STG_STEP_ATTR
+__global__ void __launch_bounds__(PC ? 2 * WGW * 64 : WGW * 64, (SOLVER != STG_SOLVER_RK45 && !THERMAL && !DEVPHYS && AXIS_Z && MULTI != 2 && !(MULTI && WGW == 1)) ? 4 : 1) STG_STEP_ATTR
 stg_step_kernel(const StepArgs a) {
     // the env-step arithmetic around the solver (energy, reward, flags) has no contraction: same roundings in every
     // instantiation, and the same as NumPy's
@@ -673,7 +678,16 @@ stg_step_kernel(const StepArgs a) {
     // (nearly) equal trip counts; all state and outputs stay at the env's own index
     const int64_t i = live ? (a.perm ? (int64_t)a.perm[lane_slot] : lane_slot) : 0;
     constexpr int ENV_LAYOUT = SOLVER == STG_SOLVER_RK45 ? ENV_LAYOUT_LLGS : (DEVPHYS ? ENV_LAYOUT_DEV : ENV_LAYOUT_CORE);
-    const double* row = class_row<MULTI>(a.ctab, a.cls, a.ncls, i, live, s_tab, a.ep, a.N, ENV_LAYOUT);
+    double own_row[MULTI == 2 ? C_COUNT : 1];
+    const double* row;
+    if constexpr (MULTI == 2) {
+        stg_device_params p;                                      // (a lane without an env reads env 0's record and never writes)
+        load_env_params<ENV_LAYOUT>(a.ep, i, p);
+        derive_row(p, a.ep.gamma, a.ep.temperature, own_row);
+        row = own_row;
+    } else {
+        row = class_row<MULTI != 0>(a.ctab, a.cls, a.ncls, i, live, s_tab, a.ep, a.N, ENV_LAYOUT);
+    }
     // Lanes without an env: the one-wavefront form has no rendezvous after this point and lets them go; in the
     // wave-specialised form they stay (inert) because every wavefront of the workgroup takes part in every s_barrier.
     if (!PC && !live) return;
@@ -911,9 +925,9 @@ __global__ void __launch_bounds__(WGW * 64) stg_step_refill_kernel(const StepArg
 constexpr int64_t STG_WG4_MIN_ENVS = 65536;       // 256 CUs x 4 SIMDs x 64 lanes
 
 // dynamic LDS of a launch: the class table of a MULTI kernel (see stg_step_kernel)
-template <bool MULTI>
+template <int MULTI>
 static size_t step_dyn_lds(const StepArgs& a) {
-    return MULTI ? (size_t)(a.ep.soa ? 64 : a.ncls) * C_COUNT * sizeof(double) : 0;
+    return MULTI == 1 ? (size_t)a.ncls * C_COUNT * sizeof(double) : 0;
 }
 
 // Grid of a step launch: under the sorted schedule whole tiles (a ragged last tile counts as one, see stg_slot_block).
@@ -959,7 +973,7 @@ static StepArgs with_snake_rule(const StepArgs& a, KernelT kernel, int wgw, size
     return b;
 }
 
-template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, bool DEVPHYS, int WGW>
+template <int SOLVER, bool THERMAL, int MULTI, bool AXIS_Z, bool DEVPHYS, int WGW>
 static void launch_step_w(const StepArgs& a, int act_f64, bool pc, hipStream_t st) {
     const dim3 grid(step_grid(a, WGW));
     const unsigned nwg = (unsigned)((a.N + WGW * 64 - 1) / (WGW * 64));
@@ -973,7 +987,7 @@ static void launch_step_w(const StepArgs& a, int act_f64, bool pc, hipStream_t s
     }
 }
 
-template <int SOLVER, bool THERMAL, bool MULTI, bool AXIS_Z, bool DEVPHYS>
+template <int SOLVER, bool THERMAL, int MULTI, bool AXIS_Z, bool DEVPHYS>
 static void launch_step(const StepArgs& a, int act_f64, bool pc, hipStream_t st) {
     if (THERMAL && !DEVPHYS && pc) {
         // wave-specialised variant: one integrating + one producing wavefront per workgroup; not built for the
@@ -991,14 +1005,21 @@ static void launch_step(const StepArgs& a, int act_f64, bool pc, hipStream_t st)
     else launch_step_w<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, 1>(a, act_f64, pc, st);
 }
 template <int SOLVER, bool AXIS_Z, bool DEVPHYS>
-static void dispatch_step2(const StepArgs& a, bool thermal, bool multi, int act_f64, bool pc, hipStream_t st) {
-    if (thermal) { if (multi) launch_step<SOLVER, true, true, AXIS_Z, DEVPHYS>(a, act_f64, pc, st); else launch_step<SOLVER, true, false, AXIS_Z, DEVPHYS>(a, act_f64, pc, st); }
-    else { if (multi) launch_step<SOLVER, false, true, AXIS_Z, DEVPHYS>(a, act_f64, false, st); else launch_step<SOLVER, false, false, AXIS_Z, DEVPHYS>(a, act_f64, false, st); }
+static void dispatch_step2(const StepArgs& a, bool thermal, int multi, int act_f64, bool pc, hipStream_t st) {
+    if (thermal) {
+        if (multi == 2) launch_step<SOLVER, true, 2, AXIS_Z, DEVPHYS>(a, act_f64, pc, st);
+        else if (multi) launch_step<SOLVER, true, 1, AXIS_Z, DEVPHYS>(a, act_f64, pc, st);
+        else launch_step<SOLVER, true, 0, AXIS_Z, DEVPHYS>(a, act_f64, pc, st);
+    } else {
+        if (multi == 2) launch_step<SOLVER, false, 2, AXIS_Z, DEVPHYS>(a, act_f64, false, st);
+        else if (multi) launch_step<SOLVER, false, 1, AXIS_Z, DEVPHYS>(a, act_f64, false, st);
+        else launch_step<SOLVER, false, 0, AXIS_Z, DEVPHYS>(a, act_f64, false, st);
+    }
 }
 // axis_z selects the easy-axis = z specialisation of the RHS (Simple: e = +z; LLGS: raw axis and demag along z);
 // devphys the opt-in device-physics torque model (fixed-step solvers only)
 template <int SOLVER>
-static void dispatch_step(const StepArgs& a, bool thermal, bool multi, bool axis_z, bool devphys, int act_f64, bool pc, hipStream_t st) {
+static void dispatch_step(const StepArgs& a, bool thermal, int multi, bool axis_z, bool devphys, int act_f64, bool pc, hipStream_t st) {
     if constexpr (SOLVER != STG_SOLVER_RK45) {          // (the device-physics torque model exists for the fixed-step solvers only)
         if (devphys) {
             if (axis_z) dispatch_step2<SOLVER, true, true>(a, thermal, multi, act_f64, pc, st);
@@ -1031,7 +1052,8 @@ static void dispatch_refill(const StepArgs& a, bool thermal, bool multi, bool ax
 }
 
 // defined in stg_step_{rk4,euler,rk45}.hip
-void stg_dispatch_step_rk4(const StepArgs& a, bool thermal, bool multi, bool axis_z, bool devphys, int act_f64, bool pc, hipStream_t st);
-void stg_dispatch_step_euler(const StepArgs& a, bool thermal, bool multi, bool axis_z, bool devphys, int act_f64, bool pc, hipStream_t st);
-void stg_dispatch_step_rk45(const StepArgs& a, bool thermal, bool multi, bool axis_z, int act_f64, bool pc, hipStream_t st);
+// (multi: 0 one class, 1 class table, 2 per-env parameter records)
+void stg_dispatch_step_rk4(const StepArgs& a, bool thermal, int multi, bool axis_z, bool devphys, int act_f64, bool pc, hipStream_t st);
+void stg_dispatch_step_euler(const StepArgs& a, bool thermal, int multi, bool axis_z, bool devphys, int act_f64, bool pc, hipStream_t st);
+void stg_dispatch_step_rk45(const StepArgs& a, bool thermal, int multi, bool axis_z, int act_f64, bool pc, hipStream_t st);
 void stg_dispatch_step_rk45_refill(const StepArgs& a, bool thermal, bool multi, bool axis_z, int act_f64, hipStream_t st);

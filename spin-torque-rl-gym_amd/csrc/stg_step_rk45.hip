@@ -1,7 +1,7 @@
 // stg_step_rk45.hip -- instantiations of the env-step kernel for STG_SOLVER_RK45 (see stg_kernels.hpp)
 #include "stg_kernels.hpp"
 
-void stg_dispatch_step_rk45(const StepArgs& a, bool thermal, bool multi, bool axis_z, int act_f64, bool pc, hipStream_t st) {
+void stg_dispatch_step_rk45(const StepArgs& a, bool thermal, int multi, bool axis_z, int act_f64, bool pc, hipStream_t st) {
     dispatch_step<STG_SOLVER_RK45>(a, thermal, multi, axis_z, false, act_f64, pc, st);
 }
 

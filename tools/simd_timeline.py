@@ -21,14 +21,22 @@ ROWS = {
     "rk4_262k": dict(n=262144, solver="rk4", thermal=0),
     "rk4th_262k": dict(n=262144, solver="rk4", thermal=1),
     "refill1m": dict(n=1048576, solver="rk45", thermal=1),
+    "refill262k": dict(n=262144, solver="rk45", thermal=1),
+    "cfg4perenv": dict(n=262144, solver="rk4", thermal=0, mixed=True, per_env=True),
+    "rk4th_131k": dict(n=131072, solver="rk4", thermal=1),
+    "rk4_131k": dict(n=131072, solver="rk4", thermal=0),
+    "rk4_1m": dict(n=1048576, solver="rk4", thermal=0),
+    "rk45_t0_131k": dict(n=131072, solver="rk45", thermal=0),
+    "rk45_t0_65k": dict(n=65536, solver="rk45", thermal=0),
+    "cfg2": dict(n=4096, solver="rk45", thermal=0),
 }
 
 
-def run(name, n, solver, thermal, mixed=False, tm="reference", steps=4):
+def run(name, n, solver, thermal, mixed=False, tm="reference", steps=4, per_env=False):
     kw = dict(include_thermal_fluctuations=bool(thermal), temperature=300.0, solver=solver, seed=1234, autoreset=True, torque_model=tm)
     cls = None
     if mixed:
-        mk, cls = bench.mixed_kwargs(solver, n)
+        mk, cls = bench.mixed_kwargs(solver, n, per_env)
         kw.update(mk)
     else:
         kw.update(device_params=bench.stt_params(bench.volume_for(solver)))
