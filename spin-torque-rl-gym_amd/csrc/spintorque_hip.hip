@@ -347,10 +347,11 @@ static int fail(int code, const std::string& msg) {
 // automatic lane refill of the RK45 step (stg_step_refill_kernel: persistent wavefronts sharing one global queue; measured on 81 921 ...
 // 1 048 576 envs, profiles/r04_refill_global_ab.txt): 1024 wavefronts -- one per SIMD -- while that leaves at most 8 envs per lane (up
 // to 524 288 envs), 2048 beyond.  From 131 073 envs at T = 0 K (up to there the one-env-per-lane launch with its two wavefronts per SIMD
-// is as fast: 131 072 envs 1.96 against 1.94 ms, 98 304 envs 1.81 against 1.87) and from 81 921 envs with the thermal field (just
-// above the hybrid wave-specialised launch; 86 016 ... 131 072 envs 3.03-3.20 -> 2.91-3.09 ms: there the launch is bound by its longest
-// env at the inline-normal loop's lone-wavefront speed either way).  Attempts between refill points: 32.
-constexpr int64_t STG_REFILL_AUTO_ENVS = 131073, STG_REFILL_AUTO_ENVS_THERMAL = 81921;
+// is as fast: 131 072 envs 1.96 against 1.94 ms, 98 304 envs 1.81 against 1.87) and from 98 305 envs with the thermal field (just
+// above the hybrid wave-specialised launch: 98 304 envs hybrid 2.81 against 2.90 ms, 106 496 envs 3.08 against 2.93; up to 131 072 envs
+// 3.1-3.2 -> 2.9-3.0 ms against one env per lane: there the launch is bound by its longest env at the inline-normal loop's
+// lone-wavefront speed either way).  Attempts between refill points: 32.
+constexpr int64_t STG_REFILL_AUTO_ENVS = 131073, STG_REFILL_AUTO_ENVS_THERMAL = 98305;
 constexpr int32_t STG_REFILL_CHECK_DEFAULT = 32;
 static inline void refill_auto(int64_t n, bool thermal, int& r, int64_t& nw) {
     r = 0; nw = 0;
@@ -392,7 +393,7 @@ struct stg_ctx {
     int32_t walk_tiles = STG_WALK_TILES_DEFAULT;   // sorted schedule: tiles an XCD group keeps in flight (stg_slot_block)
     int32_t spread_max = 256;                      // STG_SPREAD_MAX (experiments), see StepArgs
     int32_t hybrid = 1;                            // STG_HYBRID=0 switches the hybrid wave-specialised launch off (experiments)
-    int32_t hybrid_min = 768;                      // fewest producer/consumer pairs for which the hybrid launch is used (STG_HYBRID_MIN)
+    int32_t hybrid_min = -1;                       // fewest producer/consumer pairs for which the hybrid launch is used (STG_HYBRID_MIN; -1: by solver)
     int32_t refill = -1, refill_check = STG_REFILL_CHECK_DEFAULT;        // STG_REFILL experiment override of cfg.lane_refill (-1: none)
 };
 
@@ -713,7 +714,10 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
         ctx->N > STG_WAVE_SPEC_MAX_ENVS && ctx->N <= 2 * STG_WAVE_SPEC_MAX_ENVS && ctx->hybrid != 0) {
         const int64_t nblk = ((ctx->N + TILE_ENVS - 1) / TILE_ENVS) * TILE_WAVES;      // blocks of whole tiles: 1088 ... 2048
         const int64_t n_pair = 2048 - nblk;
-        if (n_pair >= ctx->hybrid_min) { pc = true; a.hybrid = (int32_t)n_pair + 1; }
+        // (measured, profiles/r04_hybrid_range_ab.txt: RK45 + thermal ahead of the refill launch up to 98 304 envs = 512 pairs, RK4 + thermal
+        // ahead of the one-env-per-lane launch up to 90 112 envs = 640 pairs)
+        const int64_t min_pairs = ctx->hybrid_min >= 0 ? ctx->hybrid_min : (ctx->cfg.solver == STG_SOLVER_RK45 ? 512 : 640);
+        if (n_pair >= min_pairs) { pc = true; a.hybrid = (int32_t)n_pair + 1; a.hybrid_prio = getenv("STG_HYB_PRIO") ? atoi(getenv("STG_HYB_PRIO")) : 1; }
     }
     // lane refill (RK45 throughput launches, see stg_step_refill_kernel).  cfg.lane_refill: 0 = automatic, -1 never, >= 2 forced;
     // experiment knob STG_REFILL=<envs per lane>[,<attempts between refill points>] overrides the configuration

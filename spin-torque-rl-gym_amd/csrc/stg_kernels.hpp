@@ -82,6 +82,7 @@ struct StepArgs {
     unsigned long long* refill_cursor_next;   // ... and the cursor of the NEXT refill launch, which this launch zeroes (two cursors alternate)
     int32_t spread_max;           // sorted schedule, 4-wavefront workgroups: up to this many workgroups a workgroup takes ranks u, u+16, u+32,
                                   // u+48 of its tile (spread), beyond it four consecutive ranks (stg_slot_block)
+    int32_t hybrid_prio;          // experiment knob (STG_HYB_PRIO=0): hybrid launch with the old numbering of the two-block workgroups
     int32_t hybrid;               // wave-specialised launch of 1024 workgroups over more than 1024 blocks: number of producer/consumer pairs + 1
                                   // (the other workgroups integrate two blocks with the normals inline); 0: every workgroup is a pair.
                                   // See stg_hybrid_block
@@ -515,12 +516,20 @@ __device__ __forceinline__ int64_t refill_slot_base(int64_t idx, int64_t tiles) 
 // second wavefront that retired at once -- which broke that structure beyond 1024 workgroups: 66 000 envs 2.60 ms.)
 // Speed heuristics only: results never depend on the schedule.
 // -> first slot of the block of wavefront `wave` (0 / 1) of workgroup b; `paired`: the workgroup is a producer/consumer pair
-__device__ __forceinline__ int64_t stg_hybrid_block(uint32_t b, int wave, uint32_t n_pair, int64_t tiles, bool& paired) {
+__device__ __forceinline__ int64_t stg_hybrid_block(uint32_t b, int wave, uint32_t n_pair, int64_t tiles, bool& paired, bool a_split = true) {
     const uint32_t r = b % 8u, q = b / 8u, round = q / 32u, p = q % 32u;            // 1024 workgroups: 128 per XCD group
     const uint32_t qq = (round == 0u) ? p : (round == 2u) ? (32u + p) : (round == 3u) ? (127u - p) : (95u - p);   // (as in stg_slot_block)
     const uint32_t k = qq * 8u + r;                                                  // rank of the workgroup, longest first
     paired = k < n_pair;
-    const int64_t blk = paired ? (int64_t)k : (int64_t)n_pair + 2 * (int64_t)(k - n_pair) + wave;
+    // A two-block workgroup takes one block of the longer half of the unpaired blocks (wavefront 0) and one of the shorter half
+    // (wavefront 1).  The CU's arrivals share SIMDs in a ring -- wavefront 1 of arrival g with wavefront 0 of arrival g+1, of the
+    // fourth with the first arrival's (measured: profiles/r04_simd_timeline.txt) -- and SIMD arbitration is by age: wavefront 1 of a
+    // two-block workgroup (the fourth, youngest arrival) sits next to the CU's LONGEST integrating wavefront and gets only the leftover
+    // slots until that one retires.  It used to take block 2j+1 next to wavefront 0's 2j -- at 81 920 envs an 867-attempt block that
+    // ended the launch at 2.65 ms, 0.9 ms after its SIMD's pair; with the shortest blocks there it ends sooner (a_split = false: the old
+    // numbering, experiments).
+    const int64_t n_in = 1024 - (int64_t)n_pair, j = (int64_t)k - (int64_t)n_pair;
+    const int64_t blk = paired ? (int64_t)k : (a_split ? (int64_t)n_pair + (wave ? n_in + j : j) : (int64_t)n_pair + 2 * j + wave);
     return blk < tiles * TILE_WAVES ? refill_slot_base(blk, tiles) : tiles * TILE_ENVS;
 }
 
@@ -666,7 +675,7 @@ stg_step_kernel(const StepArgs a) {
     // wavefronts integrate a block of their own with the normals inline (stg_hybrid_block)
     bool paired = PC;
     int64_t hyb_slot = 0;
-    if (PC && a.hybrid) hyb_slot = stg_hybrid_block(blockIdx.x, wave, (uint32_t)(a.hybrid - 1), (a.N + TILE_ENVS - 1) / TILE_ENVS, paired);
+    if (PC && a.hybrid) hyb_slot = stg_hybrid_block(blockIdx.x, wave, (uint32_t)(a.hybrid - 1), (a.N + TILE_ENVS - 1) / TILE_ENVS, paired, a.hybrid_prio != 0);
     const bool producer = PC && paired && wave >= WGW;
     const int cw = producer ? (2 * WGW - 1 - wave) : (wave < WGW ? wave : wave - WGW);   // the integrating wavefront this one is, or serves
     record_placement(a.placement, wave, lane, producer);

@@ -16,6 +16,7 @@ ROWS = {
     "headline": dict(n=65536, solver="rk45", thermal=1), "rk4th": dict(n=65536, solver="rk4", thermal=1),
     "shard": dict(n=131072, solver="rk45", thermal=1), "cfg4": dict(n=262144, solver="rk4", thermal=0, mixed=True),
     "cfg4dev": dict(n=262144, solver="rk4", thermal=0, mixed=True, tm="device"), "rk4_262k": dict(n=262144, solver="rk4", thermal=0),
+    "hyb81920": dict(n=81920, solver="rk45", thermal=1), "hyb70000": dict(n=70000, solver="rk45", thermal=1),
 }
 r = ROWS[name]
 bench.cap_host_threads()

@@ -29,6 +29,8 @@ ROWS = {
     "rk45_t0_131k": dict(n=131072, solver="rk45", thermal=0),
     "rk45_t0_65k": dict(n=65536, solver="rk45", thermal=0),
     "cfg2": dict(n=4096, solver="rk45", thermal=0),
+    "hyb81920": dict(n=81920, solver="rk45", thermal=1),
+    "hyb70000": dict(n=70000, solver="rk45", thermal=1),
 }
 
 
