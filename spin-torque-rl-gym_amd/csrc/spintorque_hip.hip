@@ -711,13 +711,15 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
     a.hybrid = 0;
     if ((ctx->cfg.solver == STG_SOLVER_RK45 || (ctx->cfg.solver == STG_SOLVER_RK4 && thermal && !devphys)) &&
         ctx->cfg.thermal && ctx->cfg.wave_spec == 0 && a.perm && !ctx->per_env &&
-        ctx->N > STG_WAVE_SPEC_MAX_ENVS && ctx->N <= 2 * STG_WAVE_SPEC_MAX_ENVS && ctx->hybrid != 0) {
-        const int64_t nblk = ((ctx->N + TILE_ENVS - 1) / TILE_ENVS) * TILE_WAVES;      // blocks of whole tiles: 1088 ... 2048
+        ctx->N > STG_WAVE_SPEC_MAX_ENVS && ctx->hybrid != 0) {
+        const int64_t nblk = ((ctx->N + TILE_ENVS - 1) / TILE_ENVS) * TILE_WAVES;      // blocks of whole tiles
+        // (a) up to 131 072 envs: pairs for the 2048 - nblk longest blocks, two fixed blocks in each other workgroup -- measured
+        // (profiles/r04_hybrid_range_ab.txt) ahead of the alternatives down to 512 pairs (RK45, 98 304 envs) / 640 pairs (RK4, 90 112 envs)
         const int64_t n_pair = 2048 - nblk;
-        // (measured, profiles/r04_hybrid_range_ab.txt: RK45 + thermal ahead of the refill launch up to 98 304 envs = 512 pairs, RK4 + thermal
-        // ahead of the one-env-per-lane launch up to 90 112 envs = 640 pairs)
         const int64_t min_pairs = ctx->hybrid_min >= 0 ? ctx->hybrid_min : (ctx->cfg.solver == STG_SOLVER_RK45 ? 512 : 640);
-        if (n_pair >= min_pairs) { pc = true; a.hybrid = (int32_t)n_pair + 1; a.hybrid_prio = getenv("STG_HYB_PRIO") ? atoi(getenv("STG_HYB_PRIO")) : 1; }
+        if (ctx->N <= 2 * STG_WAVE_SPEC_MAX_ENVS && n_pair >= min_pairs) {
+            pc = true; a.hybrid = (int32_t)n_pair + 1; a.hybrid_prio = getenv("STG_HYB_PRIO") ? atoi(getenv("STG_HYB_PRIO")) : 1;
+        }
     }
     // lane refill (RK45 throughput launches, see stg_step_refill_kernel).  cfg.lane_refill: 0 = automatic, -1 never, >= 2 forced;
     // experiment knob STG_REFILL=<envs per lane>[,<attempts between refill points>] overrides the configuration

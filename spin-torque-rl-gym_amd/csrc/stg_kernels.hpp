@@ -617,6 +617,116 @@ __device__ __forceinline__ void env_step_tail(const StepArgs& a, int64_t i, int6
     }
 }
 
+// The refill loop of ONE persistent wavefront (see stg_step_refill_kernel below, which is this loop for every wavefront of a launch).  The
+// queue holds the blocks [blk0, blk0 + nblk_q) of the rank-major order; this is wavefront w of the nw that share it.  (A device function
+// of its own since round 4's experiment of running it in the non-pair workgroups of the hybrid launch: profiles/EXPERIMENTS.md.)
+template <bool THERMAL, bool MULTI, bool AXIS_Z, typename AT>
+__device__ __forceinline__ void refill_wave(const StepArgs& a, int64_t w, int64_t nw, int64_t blk0, int64_t nblk_q, int lane, const double* s_tab,
+                                            unsigned long long& c_steps, unsigned long long& c_sub, unsigned long long& c_noop) {
+    const int64_t N = a.N;
+    const int64_t tiles = (N + TILE_ENVS - 1) / TILE_ENVS;
+    if (w == 0 && lane == 0) *a.refill_cursor_next = 0ull;      // (the next refill launch's cursor: nobody reads it during this launch)
+    const AT* act = (const AT*)a.actions;
+    const Recorder norec{};
+    const LlgsEnergyK noek{};
+    const Dp5Tab tb = make_dp5_tab();
+    InlineNormals ns;
+
+    // the lane's env in flight
+    int64_t i = 0;
+    bool has_env = false;
+    double J = 0.0, T = 0.0;
+    V3 e_tgt{0.0, 0.0, 1.0};                                    // the env's record as loaded (target, energy, step count, stream position)
+    double e_etot = 0.0;
+    int32_t e_step = 0;
+    uint32_t e_rng = 0;
+    bool e_skip = false;
+    const double* row = a.ctab;
+    LlgsK k = load_llgs(row);
+    LlgsLane L;
+    L.active = false; L.ok = true; L.rejected = false; L.attempts = 0; L.npts = 0;
+    L.y = L.f = L.m0 = V3{0.0, 0.0, 1.0};
+    L.t = L.T = L.h_abs = L.min_step = L.bJ = L.bpJ = 0.0;
+    V3 out_m{0.0, 0.0, 1.0};
+
+    // takes queue entry p (if there is one): state, action, the solve's prologue
+    auto take = [&](int64_t p, bool want) {
+        const int64_t idx = blk0 + (p >> 6);                     // block of the rank-major order
+        const bool valid_blk = want && (p >> 6) < nblk_q;
+        const int64_t slot = (valid_blk ? refill_slot_base(idx, tiles) : 0) + (p & 63);
+        const bool valid = valid_blk && slot < N;
+        if (!valid) return;
+        i = a.perm ? (int64_t)a.perm[slot] : slot;
+        V3 m;
+        bool done;
+        load_state(a.s, i, m, e_tgt, e_etot, e_step, e_rng, done);           // (kept for the tail of the env-step: no second read)
+        const uint32_t rng = e_rng;
+        if (a.perm) {
+            typedef typename std::conditional<std::is_same<AT, double>::value, double2, float2>::type AT2;
+            const AT2 aa = ((const AT2*)a.act_sorted)[slot];
+            parse_action<AT>(aa.x, aa.y, a.c.max_current, a.c.max_duration, J, T);
+        } else {
+            parse_action<AT>(act[i], act[N + i], a.c.max_current, a.c.max_duration, J, T);
+        }
+        if (MULTI) {
+            const int c = (int)a.cls[i];
+            row = s_tab + (c < a.ncls ? c : 0) * C_COUNT;
+            k = load_llgs(row);
+        }
+        const RngKey rk{a.c.seed, (uint64_t)(a.env_id0 + i), rng};
+        // with skip_done an env whose episode has ended is not integrated: it passes through the tail as inactive at the next refill point
+        e_skip = a.c.skip_done && done;
+        llgs_lane_begin<THERMAL, false, AXIS_Z>(L, out_m, m, J, T, k, row[C_BETA], row[C_BETAP], a.c.rtol, a.c.atol, a.c.max_step, rk,
+                                                norec, noek, ns, !e_skip);
+        has_env = true;
+    };
+    // finishes the lane's env: the rest of the env-step after the solve, outputs, state
+    auto finish = [&]() {
+        const SolveOut so = llgs_lane_finish<false>(L, out_m, norec, noek, ns);
+        V3 m = L.m0, tgt = e_tgt;                                // (the row the solve started from; the rest of the record from take())
+        double etot = e_etot;
+        int32_t step = e_step;
+        uint32_t rng = e_rng;
+        bool done = e_skip;                                      // (a stepped env's flag is recomputed by the tail)
+        env_step_tail(a, i, 0, true, true, !e_skip, row, (uint64_t)(a.env_id0 + i), m, tgt, etot, step, rng, done, J, T, so, c_steps, c_sub, c_noop);
+        store_state(a.s, i, m, tgt, etot, step, rng, done);
+        has_env = false;
+        L.active = false;
+    };
+
+    take(w * 64 + lane, true);
+    const int64_t g_first = nw * 64, g_total = nblk_q * 64;     // positions [g_first, g_total) go through the cursor
+    bool more = g_first < g_total;                              // wave-uniform: the queue may still hold entries
+    const int check = a.refill_check > 0 ? a.refill_check : 1;
+    for (;;) {
+        // up to `check` attempts of the whole wavefront (lanes that are through walk along, frozen) ...
+        for (int c = 0; c < check; ++c) {
+            llgs_lane_gate(L, a.c.max_attempts);
+            if (__ballot(L.active) == 0ull) break;
+            V3 z2{0.0, 0.0, 0.0}, z3{0.0, 0.0, 0.0};
+            llgs_lane_attempt<THERMAL, false, AXIS_Z>(L, out_m, k, tb, a.c.rtol, a.c.atol, a.c.max_step, norec, noek, ns, z2, z3);
+        }
+        // ... then a refill point: finished lanes write their env; every lane without an env -- finished just now, or one that drew an
+        // empty slot earlier -- takes the next entries of the global queue, in lane order
+        const bool fin = has_env && !L.active;
+        if (__ballot(fin) != 0ull || (more && __ballot(!has_env) != 0ull)) {
+            if (fin) finish();
+            const unsigned long long takers = __ballot(!has_env);
+            if (more && takers != 0ull) {
+                const int n_take = (int)__builtin_popcountll(takers), first = (int)__builtin_ctzll(takers);
+                const int rank = (int)__builtin_popcountll(takers & ((1ull << lane) - 1ull));
+                unsigned long long base = 0;
+                if (lane == first) base = atomicAdd(a.refill_cursor, (unsigned long long)n_take);
+                base = (unsigned long long)__shfl((long long)base, first);
+                const int64_t g0 = g_first + (int64_t)base;
+                take(g0 + rank, !has_env && g0 + rank < g_total);
+                more = g0 + n_take < g_total;
+            }
+        }
+        if (__ballot(has_env) == 0ull && !more) break;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // env.step kernel (A10-A14 around the solver), K fused steps per launch
 // ------------------------------------------------------------------------------------------------
@@ -815,115 +925,12 @@ __global__ void __launch_bounds__(WGW * 64) stg_step_refill_kernel(const StepArg
         for (int j = threadIdx.x; j < a.ncls * C_COUNT; j += blockDim.x) s_tab[j] = a.ctab[j];
         __syncthreads();
     }
-    const int64_t N = a.N;
-    const int64_t tiles = (N + TILE_ENVS - 1) / TILE_ENVS, nblk = tiles * TILE_WAVES, nw = a.refill_nw;   // (blocks of whole tiles)
+    const int64_t tiles = (a.N + TILE_ENVS - 1) / TILE_ENVS, nblk = tiles * TILE_WAVES, nw = a.refill_nw;   // (blocks of whole tiles)
     const int64_t w = (int64_t)blockIdx.x * WGW + wave;
     record_placement(a.placement, wave, lane, false);
-    if (w == 0 && lane == 0) *a.refill_cursor_next = 0ull;      // (the next refill launch's cursor: nobody reads it during this launch)
     if (w >= nw) return;
-    const AT* act = (const AT*)a.actions;
-    const Recorder norec{};
-    const LlgsEnergyK noek{};
-    const Dp5Tab tb = make_dp5_tab();
-    InlineNormals ns;
     unsigned long long c_steps = 0, c_sub = 0, c_noop = 0;
-
-    // the lane's env in flight
-    int64_t i = 0;
-    bool has_env = false;
-    double J = 0.0, T = 0.0;
-    V3 e_tgt{0.0, 0.0, 1.0};                                    // the env's record as loaded (target, energy, step count, stream position)
-    double e_etot = 0.0;
-    int32_t e_step = 0;
-    uint32_t e_rng = 0;
-    bool e_skip = false;
-    const double* row = a.ctab;
-    LlgsK k = load_llgs(row);
-    LlgsLane L;
-    L.active = false; L.ok = true; L.rejected = false; L.attempts = 0; L.npts = 0;
-    L.y = L.f = L.m0 = V3{0.0, 0.0, 1.0};
-    L.t = L.T = L.h_abs = L.min_step = L.bJ = L.bpJ = 0.0;
-    V3 out_m{0.0, 0.0, 1.0};
-
-    // takes queue entry p (if there is one): state, action, the solve's prologue
-    auto take = [&](int64_t p, bool want) {
-        const int64_t idx = p >> 6;                              // block of the rank-major order
-        const bool valid_blk = want && idx < nblk;
-        const int64_t slot = (valid_blk ? refill_slot_base(idx, tiles) : 0) + (p & 63);
-        const bool valid = valid_blk && slot < N;
-        if (!valid) return;
-        i = a.perm ? (int64_t)a.perm[slot] : slot;
-        V3 m;
-        bool done;
-        load_state(a.s, i, m, e_tgt, e_etot, e_step, e_rng, done);           // (kept for the tail of the env-step: no second read)
-        const uint32_t rng = e_rng;
-        if (a.perm) {
-            typedef typename std::conditional<std::is_same<AT, double>::value, double2, float2>::type AT2;
-            const AT2 aa = ((const AT2*)a.act_sorted)[slot];
-            parse_action<AT>(aa.x, aa.y, a.c.max_current, a.c.max_duration, J, T);
-        } else {
-            parse_action<AT>(act[i], act[N + i], a.c.max_current, a.c.max_duration, J, T);
-        }
-        if (MULTI) {
-            const int c = (int)a.cls[i];
-            row = s_tab + (c < a.ncls ? c : 0) * C_COUNT;
-            k = load_llgs(row);
-        }
-        const RngKey rk{a.c.seed, (uint64_t)(a.env_id0 + i), rng};
-        // with skip_done an env whose episode has ended is not integrated: it passes through the tail as inactive at the next refill point
-        e_skip = a.c.skip_done && done;
-        llgs_lane_begin<THERMAL, false, AXIS_Z>(L, out_m, m, J, T, k, row[C_BETA], row[C_BETAP], a.c.rtol, a.c.atol, a.c.max_step, rk,
-                                                norec, noek, ns, !e_skip);
-        has_env = true;
-    };
-    // finishes the lane's env: the rest of the env-step after the solve, outputs, state
-    auto finish = [&]() {
-        const SolveOut so = llgs_lane_finish<false>(L, out_m, norec, noek, ns);
-        V3 m = L.m0, tgt = e_tgt;                                // (the row the solve started from; the rest of the record from take())
-        double etot = e_etot;
-        int32_t step = e_step;
-        uint32_t rng = e_rng;
-        bool done = e_skip;                                      // (a stepped env's flag is recomputed by the tail)
-        env_step_tail(a, i, 0, true, true, !e_skip, row, (uint64_t)(a.env_id0 + i), m, tgt, etot, step, rng, done, J, T, so, c_steps, c_sub, c_noop);
-        store_state(a.s, i, m, tgt, etot, step, rng, done);
-        has_env = false;
-        L.active = false;
-    };
-
-    WaveProf prof;
-    prof.start();
-    take(w * 64 + lane, true);
-    const int64_t g_first = nw * 64, g_total = nblk * 64;       // positions [g_first, g_total) go through the cursor
-    bool more = g_first < g_total;                              // wave-uniform: the queue may still hold entries
-    const int check = a.refill_check > 0 ? a.refill_check : 1;
-    for (;;) {
-        // up to `check` attempts of the whole wavefront (lanes that are through walk along, frozen) ...
-        for (int c = 0; c < check; ++c) {
-            llgs_lane_gate(L, a.c.max_attempts);
-            if (__ballot(L.active) == 0ull) break;
-            V3 z2{0.0, 0.0, 0.0}, z3{0.0, 0.0, 0.0};
-            llgs_lane_attempt<THERMAL, false, AXIS_Z>(L, out_m, k, tb, a.c.rtol, a.c.atol, a.c.max_step, norec, noek, ns, z2, z3);
-        }
-        // ... then a refill point: finished lanes write their env; every lane without an env -- finished just now, or one that drew an
-        // empty slot earlier -- takes the next entries of the global queue, in lane order
-        const bool fin = has_env && !L.active;
-        if (__ballot(fin) != 0ull || (more && __ballot(!has_env) != 0ull)) {
-            if (fin) finish();
-            const unsigned long long takers = __ballot(!has_env);
-            if (more && takers != 0ull) {
-                const int n_take = (int)__builtin_popcountll(takers), first = (int)__builtin_ctzll(takers);
-                const int rank = (int)__builtin_popcountll(takers & ((1ull << lane) - 1ull));
-                unsigned long long base = 0;
-                if (lane == first) base = atomicAdd(a.refill_cursor, (unsigned long long)n_take);
-                base = (unsigned long long)__shfl((long long)base, first);
-                const int64_t g0 = g_first + (int64_t)base;
-                take(g0 + rank, !has_env && g0 + rank < g_total);
-                more = g0 + n_take < g_total;
-            }
-        }
-        if (__ballot(has_env) == 0ull && !more) break;
-    }
-    prof.stop(L.attempts);
+    refill_wave<THERMAL, MULTI, AXIS_Z, AT>(a, w, nw, 0, nblk, lane, s_tab, c_steps, c_sub, c_noop);
     record_retired(a.placement, wave, lane, c_sub);
     wave_add3(a.counters + (size_t)((blockIdx.x * WGW + wave) % COUNTER_STRIPES) * COUNTER_STRIDE, s_cnt + wave * 3, c_steps, c_sub, c_noop);
 }
