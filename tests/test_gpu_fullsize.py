@@ -207,7 +207,9 @@ def test_cfg3_headline_rk45_thermal_65536_vs_oracle_slices(stg):
 
 def test_cfg5_shard_rk45_thermal_131072_vs_oracle_slices(stg):
     """One cfg5 shard (1 048 576 envs over 8 GPUs = 131 072 per GPU) of the headline workload, keyed as rank 3's shard
-    (env_id0 = 3 x 131 072): the 4-wavefront thermal RK45 kernel without wave specialisation, two rounds of workgroups
+    (env_id0 = 3 x 131 072).  Since round 4 this launch takes the lane-refill kernel (1024 persistent wavefronts sharing one global
+    queue; with the thermal field from 98 305 envs) -- compared below, bit for bit, with the one-env-per-lane launch it replaced:
+    the 4-wavefront thermal RK45 kernel without wave specialisation, two rounds of workgroups
     per CU -- the boustrophedon order of the sorted schedule (csrc/stg_kernels.hpp: stg_slot_block)."""
     n, id0 = 131072, 3 * 131072
     m0, tgt, acts = _inputs(n, seed=77, steps=2)
@@ -232,9 +234,10 @@ def test_cfg5_shard_rk45_thermal_131072_vs_oracle_slices(stg):
         worst = max(worst, _cmp_slice(hip, ora, slice(s0, s0 + SLICE), TOL_RK45, ("cfg5 shard", s0)))
     print("cfg5 shard (rk45, thermal, 131072, env_id0 = 393216): worst |dm| vs oracle on slices =", worst)
     _assert_benchmarked_form_same_bits(stg, hip, c, n, m0, tgt, acts, "cfg5 shard", env_id0=id0, **kw)
-    other, c2 = _run_hip(stg, n, m0, tgt, acts, env_id0=id0, **kw, lane_sort=False)
-    _assert_same_bits(hip, other, "cfg5 shard lane_sort off")
-    assert c2 == c
+    for variant in (dict(lane_sort=False), dict(lane_refill=False), dict(lane_refill=False, lane_sort=False)):
+        other, c2 = _run_hip(stg, n, m0, tgt, acts, env_id0=id0, **kw, **variant)
+        _assert_same_bits(hip, other, ("cfg5 shard", variant))
+        assert c2 == c, (variant, c2, c)
 
 
 def test_cfg3_rk4_thermal_65536_vs_oracle_slices(stg):
@@ -337,7 +340,8 @@ def test_cfg4_per_env_parameters_262144_vs_oracle_slices(stg):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# lane refill of the RK45 step (csrc/stg_kernels.hpp: stg_step_refill_kernel), automatic above 131 072 envs
+# lane refill of the RK45 step (csrc/stg_kernels.hpp: stg_step_refill_kernel: persistent wavefronts on one global queue), automatic above
+# 131 072 envs (with the thermal field: above 98 304)
 # ------------------------------------------------------------------------------------------------------------------
 def test_lane_refill_rk45_thermal_262144_vs_oracle_slices_and_one_env_per_lane(stg):
     """VERDICT r2 item 2.  The headline workload at 262 144 envs takes the lane-refill kernel by default (4 envs per lane: a
@@ -409,7 +413,7 @@ def test_lane_refill_ragged_sizes_and_class_tables(stg, thermal):
 def test_schedule_covers_every_env_once_at_odd_sizes(stg, solver, thermal, sizes):
     """Round 3 rewrote the lane schedule for batch sizes that are no multiple of 8 tiles (32 768 envs) or of a tile (4096): rank-major
     order over all tiles, the ragged tile as a partly empty one, spread / consecutive ranks by the total workgroup count,
-    boustrophedon on the resident rounds, hybrid producer/consumer launch up to 81 920 envs, lane refill above 131 072.  The
+    boustrophedon on the resident rounds, hybrid producer/consumer launch up to 98 304 envs (RK4: 90 112), lane refill above 131 072 (thermal: 98 304).  The
     schedule must stay a permutation: every env stepped exactly once (on-device counter) and every output bit equal to the identity
     schedule's (lane_sort=False, which also switches hybrid and refill queues to the identity order)."""
     vol = 9.7e-6 if solver == "rk45" else 8.75e-11
@@ -458,10 +462,10 @@ def test_hybrid_launch_with_class_table_skip_done_and_fused_steps(stg, solver):
 @pytest.mark.parametrize("thermal", [False, True])
 def test_device_physics_schedule_at_ragged_sizes(stg, thermal):
     """The device-physics torque model groups the lanes of a tile by device kind and then renumbers the tile's 64-slot blocks by work
-    (plan kernel, launches of 98 304 ... 131 072 envs): workgroups stay type-uniform, rank order is longest-first.  A ragged tile's partly
+    (plan kernel; since round 4 at every size, kind-pure groups dealt by estimated cost): workgroups stay type-uniform, rank order is longest-first.  A ragged tile's partly
     filled group must keep its place (the step kernel's `slot < N` test): every env stepped exactly once and all bits equal to the identity
     schedule's, at sizes that end inside a block, on a block boundary, on a tile boundary, and with random class assignments."""
-    for n, seed in ((4097, 1), (70001, 2), (98304, 3), (98304 + 64 * 7, 4), (100001, 5), (126999, 6), (131072, 7), (150017, 8)):   # (regrouped: 98 304 ... 131 072)
+    for n, seed in ((4097, 1), (70001, 2), (98304, 3), (98304 + 64 * 7, 4), (100001, 5), (126999, 6), (131072, 7), (150017, 8)):   # (sizes around the round-3 regroup range)
         rng = np.random.default_rng(seed)
         cls = rng.integers(0, 3, n).astype(np.uint8) if seed % 2 else (np.arange(n) % 3).astype(np.uint8)
         m0, tgt, acts = _inputs(n, seed=n, steps=1, thi=4e-10)
