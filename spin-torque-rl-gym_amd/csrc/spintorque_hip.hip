@@ -376,7 +376,7 @@ struct stg_ctx {
     int32_t ncls = 0;
     const uint8_t* cls = nullptr;     // caller-owned device pointer
     unsigned long long* counters = nullptr;
-    unsigned long long* refill_cursor = nullptr;   // the refill launches' two alternating queue cursors (each in a 128-byte line of its own)
+    unsigned long long* refill_cursor = nullptr;   // the refill launches' two alternating sets of stripe cursors (each cursor in a 128-byte line of its own)
     uint64_t refill_seq = 0;                       // refill launches so far: launch k uses cursor k & 1 and zeroes the other
     uint32_t* placement = nullptr;    // [PLACEMENT_RING][PLACEMENT_WORDS]: where the wavefronts of the last launches ran (stg_get_placement)
     uint64_t launch_seq = 0;          // step launches so far
@@ -485,7 +485,8 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     const size_t N = (size_t)n_envs;
     const size_t rs = al(N * sizeof(EnvRec)), r4 = al(N * 4), ra = al(N * 16);
     const size_t rp = al(sizeof(uint32_t) * PLACEMENT_RING * PLACEMENT_WORDS);
-    const size_t total = rs + r4 + ra + rp + 256 + al(sizeof(double) * STG_MAX_CLASSES * C_COUNT) +
+    const size_t rc = al(2 * REFILL_STRIPES * REFILL_CURSOR_STRIDE * sizeof(unsigned long long));
+    const size_t total = rs + r4 + ra + rp + rc + al(sizeof(double) * STG_MAX_CLASSES * C_COUNT) +
                          COUNTER_STRIPES * COUNTER_STRIDE * sizeof(unsigned long long);
     hipError_t e = hipMalloc(&c->slab, total);
     if (e != hipSuccess) { delete c; return fail(STG_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
@@ -498,7 +499,7 @@ int stg_create(stg_ctx** out, int device_id, int64_t n_envs, int64_t env_id0, co
     c->perm = (uint32_t*)p; p += r4;
     c->act_sorted = (void*)p; p += ra;
     c->placement = (uint32_t*)p; p += rp;
-    c->refill_cursor = (unsigned long long*)p; p += 256;
+    c->refill_cursor = (unsigned long long*)p; p += rc;
     *out = c;
     return STG_OK;
 }
@@ -737,8 +738,8 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
             a.refill = r; a.refill_check = chk > 0 ? chk : STG_REFILL_CHECK_DEFAULT; a.refill_nw = (int32_t)nw;
             // two cursors alternate: this launch finds its own at 0 (zeroed by the previous refill launch, or by stg_create) and
             // zeroes the next one's -- launches of a context are ordered on their stream
-            a.refill_cursor = ctx->refill_cursor + (ctx->refill_seq & 1) * 16;
-            a.refill_cursor_next = ctx->refill_cursor + ((ctx->refill_seq + 1) & 1) * 16;
+            a.refill_cursor = ctx->refill_cursor + (ctx->refill_seq & 1) * (REFILL_STRIPES * REFILL_CURSOR_STRIDE);
+            a.refill_cursor_next = ctx->refill_cursor + ((ctx->refill_seq + 1) & 1) * (REFILL_STRIPES * REFILL_CURSOR_STRIDE);
             ctx->refill_seq += 1;
             stg_dispatch_step_rk45_refill(a, ctx->cfg.thermal != 0, multi != 0, ctx->axis_z_llgs, act_f64, st);
             HIP_TRY(hipGetLastError());

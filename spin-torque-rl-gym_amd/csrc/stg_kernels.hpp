@@ -78,8 +78,8 @@ struct StepArgs {
     int32_t records;              // STG_OUT_RECORDS: `obs` is the record array [K or 1][N][STG_RECORD_BYTES], reward/term/trunc unused
     int32_t refill, refill_check; // lane-refill launch (stg_step_refill_kernel): != 0 selects it; attempts between refill points
     int32_t refill_nw;            // ... and its number of (persistent) wavefronts
-    unsigned long long* refill_cursor;   // ... the cursor of its global queue (0 when the launch starts)
-    unsigned long long* refill_cursor_next;   // ... and the cursor of the NEXT refill launch, which this launch zeroes (two cursors alternate)
+    unsigned long long* refill_cursor;   // ... the cursors of its global queue's stripes (all 0 when the launch starts)
+    unsigned long long* refill_cursor_next;   // ... and the cursors of the NEXT refill launch, which this launch zeroes (two sets alternate)
     int32_t spread_max;           // sorted schedule, 4-wavefront workgroups: up to this many workgroups a workgroup takes ranks u, u+16, u+32,
                                   // u+48 of its tile (spread), beyond it four consecutive ranks (stg_slot_block)
     int32_t hybrid_prio;          // experiment knob (STG_HYB_PRIO=0): hybrid launch with the old numbering of the two-block workgroups
@@ -617,6 +617,9 @@ __device__ __forceinline__ void env_step_tail(const StepArgs& a, int64_t i, int6
     }
 }
 
+constexpr int REFILL_STRIPES = 64;            // interleaved stripes of the refill queue, one cursor each
+constexpr int REFILL_CURSOR_STRIDE = 16;      // u64 between two cursors (a 128-byte line each)
+
 // The refill loop of ONE persistent wavefront (see stg_step_refill_kernel below, which is this loop for every wavefront of a launch).  The
 // queue holds the blocks [blk0, blk0 + nblk_q) of the rank-major order; this is wavefront w of the nw that share it.  (A device function
 // of its own since round 4's experiment of running it in the non-pair workgroups of the hybrid launch: profiles/EXPERIMENTS.md.)
@@ -625,7 +628,8 @@ __device__ __forceinline__ void refill_wave(const StepArgs& a, int64_t w, int64_
                                             unsigned long long& c_steps, unsigned long long& c_sub, unsigned long long& c_noop) {
     const int64_t N = a.N;
     const int64_t tiles = (N + TILE_ENVS - 1) / TILE_ENVS;
-    if (w == 0 && lane == 0) *a.refill_cursor_next = 0ull;      // (the next refill launch's cursor: nobody reads it during this launch)
+    // (the next refill launch's cursors: nobody reads them during this launch)
+    if (w == 0 && lane < REFILL_STRIPES) a.refill_cursor_next[lane * REFILL_CURSOR_STRIDE] = 0ull;
     const AT* act = (const AT*)a.actions;
     const Recorder norec{};
     const LlgsEnergyK noek{};
@@ -695,8 +699,21 @@ __device__ __forceinline__ void refill_wave(const StepArgs& a, int64_t w, int64_
     };
 
     take(w * 64 + lane, true);
-    const int64_t g_first = nw * 64, g_total = nblk_q * 64;     // positions [g_first, g_total) go through the cursor
-    bool more = g_first < g_total;                              // wave-uniform: the queue may still hold entries
+    // The blocks behind the nw initial ones, r = 0 ... n_rest - 1 (block nw + r of the queue), are dealt over REFILL_STRIPES interleaved
+    // stripes -- stripe s holds r = s, s + S, s + 2 S, ...: every stripe runs from long to short envs -- each with a cursor of its own:
+    // a wavefront draws from stripe w % S and moves on to the next stripe when that one is empty.  (One cursor for the whole queue cost
+    // the short-pulse launch -- 1 048 576 envs of one attempt each: 14 000 atomics on ONE address in 120 us -- half its speed.)
+    const int64_t n_rest = nblk_q > nw ? nblk_q - nw : 0;
+    static_assert(REFILL_STRIPES == 64, "one lane per stripe when a wavefront looks for a stripe that still has entries");
+    int stripe = (int)(w % REFILL_STRIPES);                     // wave-uniform: the stripe the next reservation comes from
+    bool queue_open = true;                                     // wave-uniform: some stripe may still have entries
+    // entries reserved but not handed out yet (wave-uniform): [loc_q, loc_end) of stripe loc_stripe.  A wavefront whose 64 lanes are ALL
+    // idle at two refill points in a row (envs of a few attempts, all through together: the short-pulse regime) reserves four blocks at
+    // once and hands them out over the next refill points without touching memory; otherwise it reserves exactly what its idle lanes
+    // take (a reserved block waits for THIS wavefront's lanes: long envs must not be hoarded).
+    int64_t loc_q = 0, loc_end = 0;
+    int loc_stripe = 0, full_streak = 0;
+    bool more = n_rest > 0;                                     // wave-uniform: the queue may still hold entries for this wavefront
     const int check = a.refill_check > 0 ? a.refill_check : 1;
     for (;;) {
         // up to `check` attempts of the whole wavefront (lanes that are through walk along, frozen) ...
@@ -707,7 +724,8 @@ __device__ __forceinline__ void refill_wave(const StepArgs& a, int64_t w, int64_
             llgs_lane_attempt<THERMAL, false, AXIS_Z>(L, out_m, k, tb, a.c.rtol, a.c.atol, a.c.max_step, norec, noek, ns, z2, z3);
         }
         // ... then a refill point: finished lanes write their env; every lane without an env -- finished just now, or one that drew an
-        // empty slot earlier -- takes the next entries of the global queue, in lane order
+        // empty slot earlier -- takes the next entries in lane order: first what the wavefront has reserved, then a new reservation from
+        // its current stripe (ONE atomic)
         const bool fin = has_env && !L.active;
         if (__ballot(fin) != 0ull || (more && __ballot(!has_env) != 0ull)) {
             if (fin) finish();
@@ -715,12 +733,52 @@ __device__ __forceinline__ void refill_wave(const StepArgs& a, int64_t w, int64_
             if (more && takers != 0ull) {
                 const int n_take = (int)__builtin_popcountll(takers), first = (int)__builtin_ctzll(takers);
                 const int rank = (int)__builtin_popcountll(takers & ((1ull << lane) - 1ull));
-                unsigned long long base = 0;
-                if (lane == first) base = atomicAdd(a.refill_cursor, (unsigned long long)n_take);
-                base = (unsigned long long)__shfl((long long)base, first);
-                const int64_t g0 = g_first + (int64_t)base;
-                take(g0 + rank, !has_env && g0 + rank < g_total);
-                more = g0 + n_take < g_total;
+                const int64_t avail = loc_end - loc_q;
+                const int need_new = n_take > avail ? (int)(n_take - avail) : 0;
+                int64_t new_q = 0;
+                const int new_stripe = stripe;
+                if (need_new > 0 && queue_open) {
+                    const int reserve = (takers == ~0ull && full_streak >= 1) ? 4 * 64 : need_new;
+                    unsigned long long base = 0;
+                    if (lane == first) base = atomicAdd(a.refill_cursor + stripe * REFILL_CURSOR_STRIDE, (unsigned long long)reserve);
+                    base = (unsigned long long)__shfl((long long)base, first);
+                    new_q = (int64_t)base;
+                    // (entries beyond the stripe's last block do not exist; a stripe whose last entry has been reserved is used up: on to
+                    // the next one -- all of them tried: nothing left to reserve)
+                    const int64_t stripe_end = ((n_rest - stripe + REFILL_STRIPES - 1) / REFILL_STRIPES) * 64;
+                    int64_t new_end = new_q + reserve;
+                    if (new_end >= stripe_end) {
+                        new_end = stripe_end;
+                        // ... which one?  Lane s reads cursor s (a snapshot: cursors only grow, a stripe seen empty is empty): the next
+                        // stripe after this one that still has entries -- ONE vector load instead of probing the stripes one atomic
+                        // at a time (which cost the short-pulse launch a tail of up to 64 atomic round trips per wavefront)
+                        const int64_t end_l = ((n_rest - lane + REFILL_STRIPES - 1) / REFILL_STRIPES) * 64;
+                        const unsigned long long cur_l = __hip_atomic_load(a.refill_cursor + lane * REFILL_CURSOR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        unsigned long long open_s = __ballot((int64_t)cur_l < end_l);
+                        open_s &= ~(1ull << stripe);
+                        if (open_s == 0ull) queue_open = false;
+                        else {
+                            const unsigned long long after = stripe == 63 ? 0ull : (open_s >> (stripe + 1)) << (stripe + 1);
+                            stripe = (int)__builtin_ctzll(after != 0ull ? after : open_s);
+                        }
+                    }
+                    // this lane's entry: of the old reservation while it lasts, then of the new one
+                    const bool from_old = rank < avail;
+                    const int64_t q = from_old ? loc_q + rank : new_q + (rank - avail);
+                    const int st = from_old ? loc_stripe : new_stripe;
+                    const int64_t r = (q >> 6) * REFILL_STRIPES + st;                     // rest block r, slot q % 64
+                    take((nw + r) * 64 + (q & 63), !has_env && r < n_rest && (from_old || q < new_end));
+                    loc_q = new_q + need_new < new_end ? new_q + need_new : new_end;
+                    loc_end = new_end;
+                    loc_stripe = new_stripe;
+                } else {
+                    const int64_t q = loc_q + rank;
+                    const int64_t r = (q >> 6) * REFILL_STRIPES + loc_stripe;
+                    take((nw + r) * 64 + (q & 63), !has_env && q < loc_end && r < n_rest);
+                    loc_q = loc_q + n_take < loc_end ? loc_q + n_take : loc_end;
+                }
+                more = queue_open || loc_q < loc_end;
+                full_streak = takers == ~0ull ? full_streak + 1 : 0;
             }
         }
         if (__ballot(has_env) == 0ull && !more) break;
@@ -906,9 +964,10 @@ stg_step_kernel(const StepArgs a) {
 // got only what its own wavefront's queue held -- 196 608 envs 4.40 -> 3.67 ms, 262 144 envs 5.18 -> 4.49 ms).  Per-env arithmetic
 // is exactly that of stg_step_kernel (llgs_lane_begin / _attempt / _finish, env_step_tail), and an env's arithmetic never depends on
 // the lane that runs it, so results are bit-identical whatever the order the entries are taken in (tested).
-//  * Queue entry p = slot p % 64 of block p / 64 of the rank-major order; entries [0, nw * 64) are the initial envs, the rest goes
-//    through the cursor: ONE atomic per wavefront and refill point (the wavefront's takers get consecutive entries).  Two cursors
-//    alternate between launches: a launch finds its own at 0 and zeroes the next one's (no memset between launches).
+//  * Queue entry p = slot p % 64 of block p / 64 of the rank-major order; entries [0, nw * 64) are the initial envs, the blocks behind
+//    them are dealt over 64 interleaved stripes with a cursor each: ONE atomic per wavefront and refill point (the wavefront's takers
+//    get consecutive entries of its current stripe; an empty stripe sends it to the next).  Two sets of cursors alternate between
+//    launches: a launch finds its own at 0 and zeroes the next one's (no memset between launches).
 //  * A refill point -- finish the env (tail of the env-step, stores), take the next entry (state load, action, the solve's
 //    prologue: two RHS calls, initial step) -- is ~2700 instructions of lane-divergent code that the whole wavefront waits for; it
 //    is entered at most every `refill_check` attempts (lanes that finished within that window go together) or when no lane is
