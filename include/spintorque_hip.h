@@ -124,8 +124,8 @@ typedef struct {
     double noise_corr_time;         /* correlation_time of ThermalFluctuations (default 1e-12 s); used when noise_model = 1 */
     int32_t lane_refill;            /* STG_SOLVER_RK45, single-step launches: persistent wavefronts share one global queue of the launch's
                                        envs in the sorted schedule's longest-first order, and a lane that has finished its env takes the next
-                                       entry while its neighbours keep integrating (ABI v3; the queue is global since round 4).  0 = automatic
-                                       (launches of more than 131072 envs, more than 81920 with the thermal field: 1024 wavefronts -- one per
+                                       entry while its neighbours keep integrating (ABI v3; since round 4 the queue is global, striped over 64 cursors so that the atomics do not serialise).  0 = automatic
+                                       (launches of more than 131072 envs, more than 98304 with the thermal field: 1024 wavefronts -- one per
                                        SIMD -- up to 8 envs per lane on average, 2048 beyond), -1 = never, >= 2 = that many envs per lane on
                                        average (ceil(blocks / lane_refill) wavefronts).  Per-env arithmetic is untouched: results are
                                        bit-identical to the one-env-per-lane launch.  Not used with per-env parameter records, fused steps
