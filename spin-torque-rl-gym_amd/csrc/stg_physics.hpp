@@ -142,6 +142,37 @@ __device__ __forceinline__ double vgpr_const(double c) {
     return c;
 }
 
+// max(|a|, |b|) in ONE v_max_f64 with source modifiers.  (fmax(fabs(a), fabs(b)) compiles to three: the IEEE-mode lowering of fmax
+// first quiets each operand with v_max x, x, and fabs of a possibly-signalling NaN does not count as quiet.  No signalling NaN
+// exists on this path -- every value is the result of an arithmetic instruction -- and for quiet NaNs the instruction returns the
+// other operand, as fmax does.)
+__device__ __forceinline__ double fmax_abs(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// dst_i = src_i in the lanes of `mask` (a ballot), seven doubles at once: seven v_mov_b64 under EXEC = mask instead of fourteen
+// v_cndmask_b32 -- the commit of an accepted attempt (state, f(state), time).
+__device__ __forceinline__ void commit7(unsigned long long mask, double& d0, double s0, double& d1, double s1, double& d2, double s2,
+                                        double& d3, double s3, double& d4, double s4, double& d5, double s5, double& d6, double s6) {
+    // (EXEC and the mask change places by three XORs, so that no further SGPR pair is needed: the kernels sit at the SGPR limit)
+    asm("s_xor_b64 exec, exec, %[m]\n\t"
+        "s_xor_b64 %[m], exec, %[m]\n\t"
+        "s_xor_b64 exec, exec, %[m]\n\t"
+        "v_mov_b64 %[d0], %[s0]\n\t"
+        "v_mov_b64 %[d1], %[s1]\n\t"
+        "v_mov_b64 %[d2], %[s2]\n\t"
+        "v_mov_b64 %[d3], %[s3]\n\t"
+        "v_mov_b64 %[d4], %[s4]\n\t"
+        "v_mov_b64 %[d5], %[s5]\n\t"
+        "v_mov_b64 %[d6], %[s6]\n\t"
+        "s_mov_b64 exec, %[m]"
+        : [d0] "+v"(d0), [d1] "+v"(d1), [d2] "+v"(d2), [d3] "+v"(d3), [d4] "+v"(d4), [d5] "+v"(d5), [d6] "+v"(d6), [m] "+s"(mask)
+        : [s0] "v"(s0), [s1] "v"(s1), [s2] "v"(s2), [s3] "v"(s3), [s4] "v"(s4), [s5] "v"(s5), [s6] "v"(s6)
+        : "scc");
+}
+
 // 1/x: hardware seed (v_rcp_f64) + one Newton step, ~1 ulp.
 __device__ __forceinline__ double rcp_fast(double x) {
     const double y = __builtin_amdgcn_rcp(x);
@@ -458,12 +489,14 @@ struct LlgsK {              // A6 constants, with -gamma folded in (dm0 = -gamma
     double alpha;
     double ghs;             // -gamma * Brown strength: the thermal field enters as ghs * z
     double gz;              // AXIS_Z: -gamma * (hk r_z^2 - ms N_z), so that -gamma H_z(det) = gz * m_z
+    double agz;             // alpha * gz
 };
 // builds the folded constants from the class-table values (once per lane per launch)
 __device__ __forceinline__ LlgsK make_llgs(const V3& r, const V3& d, double hk, double hex, double alpha, double gamma, double hs) {
 #pragma clang fp contract(off)
     const double ng = -gamma;
-    return LlgsK{r, V3{ng * d.x, ng * d.y, ng * d.z}, ng * hk, ng * hex, alpha, ng * hs, ng * ((hk * r.z) * r.z + d.z)};
+    const double gz = ng * ((hk * r.z) * r.z + d.z);
+    return LlgsK{r, V3{ng * d.x, ng * d.y, ng * d.z}, ng * hk, ng * hex, alpha, ng * hs, gz, alpha * gz};
 }
 
 
@@ -749,39 +782,56 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
 }
 
 // A6: LLGSSolver.solve::llgs_rhs.  bJ = beta*J, bpJ = beta'*J (0 when |J| < 1e-12 or the pulse is over); ht = ghs * z is the
-// thermal field of this call already times -gamma (scale3).  With G = -gamma H:  dm = m x G + alpha m x (m x G) + torques.
+// thermal field of this call already times -gamma (scale3).  With G = -gamma H and p_hat = z (llgs_solver.py:226-235) the
+// reference's sum  m x G + alpha m x (m x G) + bJ m x (m x z) + bpJ m x z  is regrouped as
+//     dm = m x U + m x (m x W),   U = G + bpJ z,   W = alpha G + bJ z,
+// and, m being the unit vector formed two lines above,  m x (m x W) = m (m.W) - W:
+//     dm = m x U + m (m.W) - W
+// -- 18 fp64 instructions after the normalisation with the thermal field (8 at T = 0 K) instead of 26 (19) for the four separate
+// products; the two forms differ by (|m|^2 - 1) W, i.e. by the rounding of the normalisation (<= 4e-16 |W|).
 // AXIS_Z: raw easy axis = (0,0,rz) and demag factors = (0,0,Nz) (every factory default): G = ghex*m + (0,0,gz m_z) + ht.
-// The exchange placeholder hex*m (llgs_solver.py:205-209) is parallel to m, so it cancels in m x H up to a rounding
+// The exchange placeholder hex*m (llgs_solver.py:205-209) is parallel to m, so it cancels in both products up to a rounding
 // residue of ~1e-16 * hex (hex ~ 4e-6 A/m against H_k ~ 2.4e6 A/m) and is dropped there; the general form keeps it.
-template <bool THERMAL, bool AXIS_Z>
+// CHECKED: |y| > 1e-12 -> y/|y|, else +z (llgs_solver.py:97-101), behind a wave-uniform branch that is never taken in practice.
+// The prologue's two calls are CHECKED.  Inside the attempt loop the test cannot fire on a finite state (y starts as a unit vector,
+// an accepted step keeps it one to ~1e-6 and a stage point is y + h (...) with h |f| << 1), and for a NaN state the replacement is
+// unobservable: y, hence every stage point, y_new and the error norm are NaN with or without it, the attempt is rejected with
+// factor 0.2 either way, and the solve fails after the same number of attempts -- so the loop's seven calls skip the compare and
+// the branch (a lone wavefront stalls on each: compare -> VCC -> branch).
+template <bool THERMAL, bool AXIS_Z, bool CHECKED = true>
 __device__ __forceinline__ V3 llgs_rhs(const V3& y, const LlgsK& k, double bJ, double bpJ, const V3& ht) {
-    // |y| > 1e-12 -> y/|y|, else +z (llgs_solver.py:97-101).  |y| stays within 1e-6 of 1 on this path, so the
-    // degenerate case is handled behind a wave-uniform branch that is never taken in practice.
+#pragma clang fp contract(off)
     const double ss = dot(y, y);
     const double inv = rsqrt_fast(ss);
     V3 m{y.x * inv, y.y * inv, y.z * inv};
-    const bool unit = ss > 1e-24;
-    if (__builtin_expect(__ballot(!unit) != 0ull, 0)) m = V3{unit ? m.x : 0.0, unit ? m.y : 0.0, unit ? m.z : 1.0};
-    V3 dm;                                                                  // m x G
-    if (AXIS_Z) {
-        const double g = k.gz * m.z;
-        if (THERMAL) dm = cross(m, V3{ht.x, ht.y, ht.z + g});
-        else dm = V3{m.y * g, -(m.x * g), 0.0};
-    } else {
-        const double c = k.ghk * dot(m, k.r);
-        V3 h{(c * k.r.x + k.gd.x * m.x) + k.ghex * m.x, (c * k.r.y + k.gd.y * m.y) + k.ghex * m.y,
-             (c * k.r.z + k.gd.z * m.z) + k.ghex * m.z};
-        if (THERMAL) h = V3{h.x + ht.x, h.y + ht.y, h.z + ht.z};                            // llgs_solver.py:111-113
-        dm = cross(m, h);
+    if (CHECKED) {
+        const bool unit = ss > 1e-24;
+        if (__builtin_expect(__ballot(!unit) != 0ull, 0)) m = V3{unit ? m.x : 0.0, unit ? m.y : 0.0, unit ? m.z : 1.0};
     }
-    V3 mxdm;
-    if (AXIS_Z && !THERMAL) mxdm = V3{-(m.z * dm.y), m.z * dm.x, __builtin_fma(m.x, dm.y, -(m.y * dm.x))};   // dm.z = 0
-    else mxdm = cross(m, dm);
-    dm = V3{dm.x + k.alpha * mxdm.x, dm.y + k.alpha * mxdm.y, dm.z + k.alpha * mxdm.z};   // llgs_solver.py:123
-    // p_hat = z: m x z = (my, -mx, 0); m x (m x z) = (mx mz, my mz, -(mx^2 + my^2))        llgs_solver.py:226-235
-    const double uz = -__builtin_fma(m.x, m.x, m.y * m.y);
-    return V3{__builtin_fma(bJ, m.x * m.z, __builtin_fma(bpJ, m.y, dm.x)), __builtin_fma(bJ, m.y * m.z, __builtin_fma(-bpJ, m.x, dm.y)),
-              __builtin_fma(bJ, uz, dm.z)};
+    if (AXIS_Z) {
+        const double u = __builtin_fma(k.gz, m.z, bpJ);                         // U = ht + u z
+        const double w = __builtin_fma(k.agz, m.z, bJ);                         // W = alpha ht + w z
+        if (!THERMAL) {
+            const double c = m.z * w;                                           // m.W
+            return V3{__builtin_fma(m.x, c, m.y * u), __builtin_fma(m.y, c, -(m.x * u)), __builtin_fma(m.z, c, -w)};
+        }
+        const double uz = ht.z + u;                                             // llgs_solver.py:111-113
+        const V3 W{k.alpha * ht.x, k.alpha * ht.y, __builtin_fma(k.alpha, ht.z, w)};
+        const double s = dot(m, W);
+        return V3{__builtin_fma(m.x, s, __builtin_fma(m.y, uz, __builtin_fma(-m.z, ht.y, -W.x))),
+                  __builtin_fma(m.y, s, __builtin_fma(m.z, ht.x, __builtin_fma(-m.x, uz, -W.y))),
+                  __builtin_fma(m.z, s, __builtin_fma(m.x, ht.y, __builtin_fma(-m.y, ht.x, -W.z)))};
+    }
+    const double c = k.ghk * dot(m, k.r);
+    V3 g{(c * k.r.x + k.gd.x * m.x) + k.ghex * m.x, (c * k.r.y + k.gd.y * m.y) + k.ghex * m.y,
+         (c * k.r.z + k.gd.z * m.z) + k.ghex * m.z};
+    if (THERMAL) g = V3{g.x + ht.x, g.y + ht.y, g.z + ht.z};                                // llgs_solver.py:111-113
+    const V3 U{g.x, g.y, g.z + bpJ};
+    const V3 W{k.alpha * g.x, k.alpha * g.y, __builtin_fma(k.alpha, g.z, bJ)};
+    const double s = dot(m, W);
+    return V3{__builtin_fma(m.x, s, __builtin_fma(m.y, U.z, __builtin_fma(-m.z, U.y, -W.x))),
+              __builtin_fma(m.y, s, __builtin_fma(m.z, U.x, __builtin_fma(-m.x, U.z, -W.y))),
+              __builtin_fma(m.z, s, __builtin_fma(m.x, U.y, __builtin_fma(-m.y, U.x, -W.z)))};
 }
 
 struct LlgsEnergyK {
@@ -888,9 +938,9 @@ __device__ __forceinline__ void llgs_lane_emit(LlgsLane& L, V3& out_m, const Rec
 // fl(t + h) on the step that is clamped to end at T: every other stage time is fl(t + fl(c h)) with c <= 8/9, hence
 // <= t_new <= T by monotonic rounding, and an unclamped fl(t + h) is within an ulp of t_new < T.  So only k6 / f_new of an
 // attempt test the gate (`on`).
-template <bool THERMAL, bool AXIS_Z>
+template <bool THERMAL, bool AXIS_Z, bool CHECKED = true>
 __device__ __forceinline__ V3 llgs_fun(const LlgsLane& L, const LlgsK& k, const V3& y, const V3& ht, bool on) {
-    return llgs_rhs<THERMAL, AXIS_Z>(y, k, on ? L.bJ : 0.0, on ? L.bpJ : 0.0, ht);
+    return llgs_rhs<THERMAL, AXIS_Z, CHECKED>(y, k, on ? L.bJ : 0.0, on ? L.bpJ : 0.0, ht);
 }
 // the thermal field of one RHS call (already times -gamma); EVEN selects the normal-stream phase (calls alternate).  Fetch and
 // evaluation are separate so that a loop can fetch call j+1's field before it evaluates call j: with the shared source a
@@ -972,11 +1022,10 @@ __device__ __forceinline__ void llgs_lane_attempt(LlgsLane& L, V3& out_m, const 
     const bool active = L.active;
     const V3 y = L.y;
     const double t = L.t;
-    auto fun = [&](const V3& yy, const V3& ht, bool on) -> V3 { return llgs_fun<THERMAL, AXIS_Z>(L, k, yy, ht, on); };
+    auto fun = [&](const V3& yy, const V3& ht, bool on) -> V3 { return llgs_fun<THERMAL, AXIS_Z, false>(L, k, yy, ht, on); };
     auto draw = [&](bool even) -> V3 { return llgs_draw<THERMAL>(ns, k, even); };
     L.attempts += active ? 1 : 0;
-    double t_new = add_x(t, L.h_abs);
-    if (t_new - T > 0.0) t_new = T;
+    const double t_new = fmin(add_x(t, L.h_abs), T);                       // rk.py:135-138: if t_new - T > 0: t_new = T
     const double h = sub_x(t_new, t);
     const double h_try = fabs(h);
     // rk_step (rk.py:14-70); the one stage time that can pass T is formed without contraction
@@ -1007,8 +1056,7 @@ __device__ __forceinline__ void llgs_lane_attempt(LlgsLane& L, V3& out_m, const 
     const V3 ev{(k1.x * E1 + k3.x * E3 + k4.x * E4 + k5.x * E5 + k6.x * E6 + f_new.x * E7) * h,
                 (k1.y * E1 + k3.y * E3 + k4.y * E4 + k5.y * E5 + k6.y * E6 + f_new.y * E7) * h,
                 (k1.z * E1 + k3.z * E3 + k4.z * E4 + k5.z * E5 + k6.z * E6 + f_new.z * E7) * h};
-    const V3 sc{atol + fmax(fabs(y.x), fabs(y_new.x)) * rtol, atol + fmax(fabs(y.y), fabs(y_new.y)) * rtol,
-                atol + fmax(fabs(y.z), fabs(y_new.z)) * rtol};
+    const V3 sc{atol + fmax_abs(y.x, y_new.x) * rtol, atol + fmax_abs(y.y, y_new.y) * rtol, atol + fmax_abs(y.z, y_new.z) * rtol};
     // error_norm = rms(ev / scale) (rk.py:104-109); the controller only needs err < 1 and err^-0.2, so the kernel
     // carries err^2 (no sqrt) and divides by reciprocal-multiply (v_rcp_f64 + one Newton step, ~1 ulp)
     const V3 q{ev.x * rcp_fast(sc.x), ev.y * rcp_fast(sc.y), ev.z * rcp_fast(sc.z)};
@@ -1024,16 +1072,16 @@ __device__ __forceinline__ void llgs_lane_attempt(LlgsLane& L, V3& out_m, const 
     double fa = fmin(10.0, r9);
     fa = L.rejected ? fmin(1.0, fa) : fa;
     const double fr = fmax(0.2, r9);
-    double h_abs = active ? h_try * (acc ? fa : fr) : L.h_abs;
+    // h_abs of a lane that is through (or never started) is dead: nothing reads it before llgs_lane_begin writes it again
+    const double h_next = h_try * (acc ? fa : fr);
     // an accepted attempt advances, records, and does the next step()'s prologue
-    L.t = acc ? t_new : t;
-    L.y = V3{acc ? y_new.x : y.x, acc ? y_new.y : y.y, acc ? y_new.z : y.z};
-    L.f = V3{acc ? f_new.x : L.f.x, acc ? f_new.y : L.f.y, acc ? f_new.z : L.f.z};
+    commit7(__ballot(acc), L.t, t_new, L.y.x, y_new.x, L.y.y, y_new.y, L.y.z, y_new.z, L.f.x, f_new.x, L.f.y, f_new.y, L.f.z, f_new.z);
     if (RECORD) { if (acc) llgs_lane_emit<RECORD>(L, out_m, rec, ek); } else L.npts += acc ? 1 : 0;
     L.rejected = active ? !acc : L.rejected;
     L.min_step = llgs_min_step_at(L.t);                                                  // unchanged t -> unchanged value
-    const double hc = h_abs > max_step ? max_step : (h_abs < L.min_step ? L.min_step : h_abs);
-    L.h_abs = acc ? hc : h_abs;
+    // the next step()'s clamp of h_abs to [min_step, max_step] (rk.py:121-126) applies after an accepted attempt only; a rejected
+    // one has shrunk h_try <= max_step, so the upper clamp is a no-op there and runs unconditionally
+    L.h_abs = fmax(fmin(h_next, max_step), acc ? L.min_step : 0.0);
     L.active = active && (L.t != T);
 }
 
