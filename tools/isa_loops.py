@@ -9,7 +9,7 @@ path, key = sys.argv[1], sys.argv[2]
 min_len = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 lines = open(path).read().split("\n")
 start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and ":" in l and key in l.split(":")[0])
-end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))       # (a kernel may hold several s_endpgm)
 body = lines[start:end + 1]
 labels, insts = {}, []
 for l in body:
