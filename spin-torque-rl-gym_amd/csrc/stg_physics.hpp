@@ -128,8 +128,9 @@ __device__ __forceinline__ double sub_x(double a, double b) {
 
 // 1/sqrt(s) for s in [1e-24, DBL_MAX]: hardware seed (v_rsq_f64) + one third-order correction, ~1 ulp.
 // Replaces sqrt + three IEEE divisions per normalisation (the reference's m / |m|); the quotient differs from the
-// correctly rounded one by <= 2 ulp per component.  s = +inf gives 0, so a finite vector whose squared norm
-// overflowed still becomes the all-zero row the reference produces.
+// correctly rounded one by <= 2 ulp per component.  s = 0, +inf or NaN give NaN (0 * inf in the correction): a row whose squared
+// norm over- or underflowed poisons its solve, which then fails and returns the row it was given
+// (tests/test_gpu_parity.py: test_rk45_pathological_start_rows_vs_oracle; the fixed-step path has its own tiers, simple_validate).
 __device__ __forceinline__ double rsqrt_fast(double s) {
     const double y = __builtin_amdgcn_rsq(s);
     const double e = __builtin_fma(-(s * y), y, 1.0);
@@ -605,7 +606,7 @@ __device__ __forceinline__ int simple_validate(V3& m, bool& zero_row) {
         return 0;
     }
     const double s = dot(m, m);
-    const double inv = near1 ? inv1 : rsqrt_fast(s);   // s = inf (finite m, overflowed norm) -> inv = 0 -> zero row
+    const double inv = near1 ? inv1 : rsqrt_fast(s);   // (s = inf -- finite m, overflowed norm: the reference's zero row -- is flagged below)
     // ordinary case for the whole wavefront: 1e-24 <= |m|^2 <= DBL_MAX implies finite components (a NaN or inf
     // component makes s NaN or inf) -- the special cases sit behind a wave-uniform branch
     const bool ordinary = (s >= 1e-24) && (s <= 1.7976931348623157e308);
