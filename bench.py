@@ -395,7 +395,7 @@ def run_config(n_local, solver, thermal, steps, warmup, rank, world, device_inde
     out = dict(wall_s=last["wall_max_s"], placement=last["placement"], kernel_ms=[round(x, 4) for x in last["kernel_ms"]], device_span_s=last["device_span_s"], kernel_ms_avg=float(np.mean(last["kernel_ms"])),
                kernel_ms_min=float(np.min(last["kernel_ms"])), env_steps=c["env_steps"], work_units=c["work_units"],
                noop_steps=c["noop_steps"], launches=steps, warmup=warmup, **block_report(blocks))
-    out.update(gather_only_ms=None, wall_no_gather_s=None, api_ms_per_step=None)
+    out.update(gather_only_ms=None, wall_no_gather_s=None, api_ms_per_step=None, lane_sort=lane_sort)
     if world > 1 and extras:
         # SURVEY 8e "report both": a learner that is data-parallel over the same ranks needs no gather at all
         out["wall_no_gather_s"] = timer.timed(lambda k: one_step(warmup + k, gather=False), None, retime, tag + " no-gather")[0]["wall_max_s"]
@@ -696,12 +696,22 @@ def pmc_for_run(args, argv, world=1):
                                f"measured with --steps {committed.get('steps')})")
 
 
-def traffic_bytes(c):
-    """HBM bytes per launch: FETCH_SIZE x 2 (gfx950: 128-B read requests tallied at 64 B -- MI355X_MICROARCH.md for 16-B-per-lane
-    loads, profiles/r01f_hbm_counter_calibration.txt for 4/8-B-per-lane loads) + WRITE_SIZE (exact), both reported in KB."""
+def traffic_bytes(c, coalesced_read_bytes=None):
+    """HBM bytes per launch from FETCH_SIZE / WRITE_SIZE (both reported in KB).  gfx950 tallies the 128-B read requests of a coalesced
+    stream at 64 B: FETCH_SIZE reads HALF the bytes there (MI355X_MICROARCH.md for 16-B-per-lane loads;
+    profiles/r01f_hbm_counter_calibration.txt for 4/8-B-per-lane loads) -- and EXACTLY the bytes of scattered 64-byte records, whether
+    64, 8 or 1 lanes of a wavefront read one each (profiles/r04_hbm_scatter_calibration.txt: what a lane of the duration-sorted
+    schedule or a refill point does with its env's state record).  WRITE_SIZE is exact (sector-granular: a scattered 56-byte record
+    costs 80-85 B, same file).
+    coalesced_read_bytes = None: every read of the launch is a coalesced stream (identity schedule, the array env): 2 x FETCH_SIZE.
+    Otherwise the launch reads scattered records plus `coalesced_read_bytes` of coalesced streams (the step's actions and the
+    permutation, in slot order): FETCH_SIZE = scattered + coalesced / 2, so reads = FETCH_SIZE + coalesced / 2 (never more than
+    2 x FETCH_SIZE)."""
     if not c or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
         return None
-    return int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+    fetch, write = c["FETCH_SIZE"] * 1024.0, c["WRITE_SIZE"] * 1024.0
+    reads = 2.0 * fetch if coalesced_read_bytes is None else min(2.0 * fetch, fetch + 0.5 * coalesced_read_bytes)
+    return int(reads + write)
 
 
 def exec_block(c, kernel_s):
@@ -727,11 +737,19 @@ def roofline_step(meas, n_local, solver, mixed, pmc_row, pmc_src, per_env=False)
     we = flops_per_unit * units_per_launch / t / 1e12
     bytes_per_launch = bpe * n_local
     gbs = bytes_per_launch / t / 1e9
-    tb = traffic_bytes(c)
+    # under the duration-sorted schedule (every step row of this bench: random pulse durations) a lane's 64-B state record is a scattered
+    # read, counted at face value; only the actions (8 B), the permutation (4 B) and the class index (1 B) are coalesced streams
+    sorted_schedule = meas.get("lane_sort") is not False
+    tb = traffic_bytes(c, (13 if mixed else 12) * n_local if sorted_schedule else None)
+    tb_doubled = traffic_bytes(c)
     return {"bound": "valu_fp64", "achieved": round(ex["tflops"], 4) if ex else None, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ex["tflops"] / PEAK_FP64_VALU_TFLOPS, 5) if ex else None,
             "traffic": tb, "algorithmic_bytes": bytes_per_launch,
             "traffic_over_algorithmic": round(tb / bytes_per_launch, 3) if tb else None,
+            "traffic_basis": ("FETCH_SIZE (scattered 64-B state records: counted exactly) + half the coalesced streams' bytes (actions, "
+                              "permutation: counted at half) + WRITE_SIZE; calibration profiles/r04_hbm_scatter_calibration.txt"
+                              if sorted_schedule else "2 x FETCH_SIZE (coalesced streams) + WRITE_SIZE"),
+            "traffic_if_all_reads_doubled": tb_doubled,
             "basis": "executed: 64 x (2 FMA_F64 + MUL_F64 + ADD_F64) wavefront instructions per launch (hardware counters) / "
                      "HIP-event kernel time",
             "valu_issue_frac": round(ex["valu_issue_frac"], 4) if ex and ex["valu_issue_frac"] is not None else None,
