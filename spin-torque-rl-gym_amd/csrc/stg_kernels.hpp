@@ -831,7 +831,7 @@ stg_step_kernel(const StepArgs a) {
     // producer has slack and parks at the barrier for free, Euler's chunk is too short to pay for the polling)
     constexpr bool BARRIER = SOLVER != STG_SOLVER_RK4;
     constexpr int DEPTH = BARRIER ? 2 : 4;
-    constexpr int RING = DEPTH * SHARED_CHUNK_MAX * 64;
+    constexpr int RING = DEPTH * (FIELD ? SHARED_CHUNK_RK45 : SHARED_CHUNK_FIXED) * 64;
     static_assert(!PC || WGW == 1, "the wave-specialised form is one integrating + one producing wavefront");
     __shared__ NT s_norm[PC ? RING : 1];
     __shared__ int s_hs[2], s_go[2 * WGW];
@@ -874,11 +874,11 @@ stg_step_kernel(const StepArgs a) {
 
     if (producer) {
         // per env-step: wait for the stream positions (H1), then stay one chunk ahead of integrating wavefront `cw`.
-        // Normals per chunk: RK45 6 (initial step) then 18 per attempt; the fixed-step solvers 12 = one RK4 sub-step
-        // with the white field, or four sub-steps of Euler / of the Ornstein-Uhlenbeck field (3 each)
-        constexpr int n_first = SOLVER == STG_SOLVER_RK45 ? 6 : 12;     // (Euler / OU: SHARED_SUBS3 sub-steps of 3)
-        static_assert(3 * SHARED_SUBS3 == 12, "chunk size of the 3-normal sub-steps");
-        constexpr int n_chunk = SOLVER == STG_SOLVER_RK45 ? 18 : n_first;
+        // Normals per chunk: RK45 6 (initial step) then 18 per attempt; the fixed-step solvers SHARED_CHUNK_FIXED = 24: two RK4
+        // sub-steps with the white field, or eight sub-steps of Euler / of the Ornstein-Uhlenbeck field (3 each)
+        constexpr int n_first = SOLVER == STG_SOLVER_RK45 ? 6 : SHARED_CHUNK_FIXED;     // (Euler / OU: SHARED_SUBS3 sub-steps of 3)
+        static_assert(3 * SHARED_SUBS3 == SHARED_CHUNK_FIXED, "chunk size of the 3-normal sub-steps");
+        constexpr int n_chunk = SOLVER == STG_SOLVER_RK45 ? SHARED_CHUNK_RK45 : n_first;
         const double ghs = FIELD ? load_llgs(row).ghs : 0.0;
         for (int k = 0; k < a.K; ++k) {
             __syncthreads();                                       // H1: s_rng / s_go[k & 1] published

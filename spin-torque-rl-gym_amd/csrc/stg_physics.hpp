@@ -352,8 +352,15 @@ struct InlineNormals {
     __device__ __forceinline__ bool chunk_end(bool lane_continues) { return lane_continues; }
 };
 
-constexpr int SHARED_CHUNK_MAX = 18;     // normals per chunk: RK45 attempt 18, RK4 sub-step 12, Euler 3, RK45 prologue 6
-constexpr int SHARED_SUBS3 = 4;          // sub-steps per chunk for the solvers that draw 3 normals per sub-step
+// A chunk of the shared stream (one rendezvous of an integrating wavefront with its producer): an RK45 attempt (18 normals; the
+// prologue's chunk 0 holds 6), or -- fixed-step solvers -- SHARED_SUBS_RK4 RK4 sub-steps with the white field (12 normals each) =
+// SHARED_SUBS3 sub-steps of the forms that draw 3 per sub-step (Euler, the Ornstein-Uhlenbeck field).  Two RK4 sub-steps per chunk
+// instead of one (round 4): RK4 + thermal 32 768 envs 0.518 -> 0.489 ms, 65 536 envs 0.544 -> 0.534, Euler 0.339 -> 0.330; four per
+// chunk with a ring of two chunks: worse (0.546 / 0.570); a ring of 8 two-sub-step chunks no longer fits four workgroups per CU.
+constexpr int SHARED_SUBS_RK4 = 2;
+constexpr int SHARED_SUBS3 = 4 * SHARED_SUBS_RK4;
+constexpr int SHARED_CHUNK_FIXED = 12 * SHARED_SUBS_RK4;     // normals per chunk of the fixed-step solvers
+constexpr int SHARED_CHUNK_RK45 = 18;
 constexpr int PC_STOP = 1 << 30;
 constexpr int PC_SPIN_CAP = 1 << 22;
 
@@ -383,15 +390,16 @@ __device__ __forceinline__ void pc_store(int* p, int v) {
 // scaling of every RHS call).  DEPTH = chunks in the ring (a power of two; 2 with BARRIER).
 template <typename T, bool SCALED, int DEPTH, bool BARRIER>
 struct SharedNormalsT {
+    static constexpr int CHUNK = SCALED ? SHARED_CHUNK_RK45 : SHARED_CHUNK_FIXED;    // (the RK45 kernels hand over finished fields)
     static_assert(!BARRIER || DEPTH == 2, "the barrier form runs the producer exactly one chunk ahead");
     static constexpr bool kShared = true, kScaled = SCALED;
-    const T* buf;           // this workgroup's LDS ring [DEPTH][SHARED_CHUNK_MAX][64]
+    const T* buf;           // this workgroup's LDS ring [DEPTH][CHUNK][64]
     int* hs;                // LDS: the handshake words / BARRIER: the integrator's "continues" flag, two alternating copies
     int lane, it, idx, seen;   // seen: the producer's count as last read (a lane-uniform value in a VGPR)
     bool broken;               // the poll budget ran out (never, unless the protocol is broken): the solve reports failure
     __device__ __forceinline__ void begin(const RngKey&) { it = 0; idx = 0; seen = 1; broken = false; }    // chunk 0 is there (H2)
     __device__ __forceinline__ V3 draw(bool) {
-        const T* b = buf + ((it & (DEPTH - 1)) * SHARED_CHUNK_MAX + idx) * 64 + lane;
+        const T* b = buf + ((it & (DEPTH - 1)) * CHUNK + idx) * 64 + lane;
         idx += 3;
         return V3{(double)b[0], (double)b[64], (double)b[128]};
     }
@@ -438,7 +446,7 @@ __device__ __forceinline__ void produce_normals(T* buf, int* hs, int lane, const
     ns.init(rk.seed, rk.env_id, rk.env_step, 0u);
     bool even = true;
     auto fill = [&](int slot, int count) {
-        T* b = buf + (slot * SHARED_CHUNK_MAX) * 64 + lane;
+        T* b = buf + (slot * (SCALED ? SHARED_CHUNK_RK45 : SHARED_CHUNK_FIXED)) * 64 + lane;
         for (int j = 0; j < count; j += 3) {
             V3 z = even ? ns.draw3_even() : ns.draw3_odd();
             if (SCALED) z = scale3(c, z);
@@ -757,10 +765,10 @@ __device__ __forceinline__ SolveOut simple_solve(const V3& m0, double J, double 
         if (RECORD) rec.put(i + 1, last ? T : mul_x((double)(i + 1), dt), m, 0.0);
     };
     if (NSRC::kShared) {
-        // a chunk of the shared stream is 12 normals: one RK4 sub-step with the white field, or SHARED_SUBS3 sub-steps
-        // of the forms that take three per sub-step (Euler, the Ornstein-Uhlenbeck field) -- the rendezvous with the
-        // producer costs about as much as one Euler sub-step, so it is paid once per four
-        constexpr int SUBS = (METHOD == 1 || ou) ? SHARED_SUBS3 : 1;
+        // a chunk of the shared stream is SHARED_CHUNK_FIXED normals: SHARED_SUBS_RK4 RK4 sub-steps with the white field, or
+        // SHARED_SUBS3 sub-steps of the forms that take three per sub-step (Euler, the Ornstein-Uhlenbeck field) -- the
+        // rendezvous with the producer costs about as much as one Euler sub-step
+        constexpr int SUBS = (METHOD == 1 || ou) ? SHARED_SUBS3 : SHARED_SUBS_RK4;
         for (int i = 0;; ++i) {
             if (i < n) substep(i, std::integral_constant<int, 2>{});
             if (SUBS == 1 || (i & (SUBS - 1)) == SUBS - 1) {
