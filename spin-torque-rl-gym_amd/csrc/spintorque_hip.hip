@@ -350,7 +350,7 @@ static int fail(int code, const std::string& msg) {
 // is as fast: 131 072 envs 1.96 against 1.94 ms, 98 304 envs 1.81 against 1.87) and from 98 305 envs with the thermal field (just
 // above the hybrid wave-specialised launch: 98 304 envs hybrid 2.81 against 2.90 ms, 106 496 envs 3.08 against 2.93; up to 131 072 envs
 // 3.1-3.2 -> 2.9-3.0 ms against one env per lane: there the launch is bound by its longest env at the inline-normal loop's
-// lone-wavefront speed either way).  Attempts between refill points: 32.
+// lone-wavefront speed either way).  Attempts between refill points: 32 (16 with 2048 wavefronts).
 constexpr int64_t STG_REFILL_AUTO_ENVS = 131073, STG_REFILL_AUTO_ENVS_THERMAL = 98305;
 constexpr int32_t STG_REFILL_CHECK_DEFAULT = 32;
 static inline void refill_auto(int64_t n, bool thermal, int& r, int64_t& nw) {
@@ -729,7 +729,12 @@ int stg_step_many(stg_ctx* ctx, int32_t K, const void* actions, int32_t act_f64,
         const int64_t nblk = ((ctx->N + TILE_ENVS - 1) / TILE_ENVS) * TILE_WAVES;
         int r = 0, chk = STG_REFILL_CHECK_DEFAULT;
         int64_t nw = 0;
-        if (ctx->cfg.lane_refill == 0) refill_auto(ctx->N, ctx->cfg.thermal != 0, r, nw);
+        if (ctx->cfg.lane_refill == 0) {
+            refill_auto(ctx->N, ctx->cfg.thermal != 0, r, nw);
+            // (two wavefronts per SIMD: a refill point every 16 attempts -- 1 048 576 envs 13.3 against 13.6 ms; with one per SIMD 16 ... 64
+            // are alike, 8 and 128 worse: tools/refill_check_sweep.py)
+            if (nw >= 2048) chk = 16;
+        }
         else if (ctx->cfg.lane_refill > 0) { r = ctx->cfg.lane_refill; nw = (nblk + r - 1) / r; }
         if (ctx->refill >= 0) { r = ctx->refill; chk = ctx->refill_check; nw = r >= 2 ? (nblk + r - 1) / r : 0; }
         // (not combined with the wave-specialised launch: a forced wave_spec = 1 keeps the one-env-per-lane kernel)
