@@ -1014,15 +1014,14 @@ static inline unsigned step_grid(const StepArgs& a, int wgw) {
 }
 
 // Workgroups of this kernel a CU holds at once (registers, LDS), asked of the runtime once per (kernel, LDS size) and thread.
-template <class KernelT>
-static int resident_workgroups_per_cu(KernelT kernel, int block, size_t lds) {
+static int resident_workgroups_per_cu(const void* kernel, int block, size_t lds) {
     struct Key { const void* f; size_t lds; int v; };
     static thread_local Key cache[8] = {};
     static thread_local int used = 0;
-    for (int j = 0; j < used; ++j) if (cache[j].f == (const void*)kernel && cache[j].lds == lds) return cache[j].v;
+    for (int j = 0; j < used; ++j) if (cache[j].f == kernel && cache[j].lds == lds) return cache[j].v;
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, lds) != hipSuccess || nb < 1) nb = 2;
-    if (used < 8) cache[used++] = Key{(const void*)kernel, lds, nb};
+    if (used < 8) cache[used++] = Key{kernel, lds, nb};
     return nb;
 }
 
@@ -1033,8 +1032,7 @@ static int resident_workgroups_per_cu(KernelT kernel, int block, size_t lds) {
 // four wavefronts per CU (262 144 envs = four rounds, all resident: cfg4 0.532 -> 0.500 ms, RK4 at T = 0 K 0.54 -> 0.49 ms), the
 // device-physics and thermal ones three or two.  So the host asks the runtime and the boustrophedon applies to that many leading
 // rounds (a launch a little over two rounds keeps its first two balanced: RK4 + thermal 132 000 envs).
-template <class KernelT>
-static StepArgs with_snake_rule(const StepArgs& a, KernelT kernel, int wgw, size_t lds, unsigned nwg) {
+static StepArgs with_snake_rule(const StepArgs& a, const void* kernel, int wgw, size_t lds, unsigned nwg) {
     StepArgs b = a;
     if (!a.perm || (a.walk & (int32_t)(STG_WALK_SNAKE_ON | STG_WALK_SNAKE_OFF))) return b;          // identity schedule / forced by STG_SNAKE
     const unsigned tile_wgs = (unsigned)(TILE_WAVES / wgw), n_q = ((nwg + tile_wgs - 1) / tile_wgs) * tile_wgs / 8u;   // workgroups per XCD group
@@ -1053,12 +1051,14 @@ static void launch_step_w(const StepArgs& a, int act_f64, bool pc, hipStream_t s
     const dim3 grid(step_grid(a, WGW));
     const unsigned nwg = (unsigned)((a.N + WGW * 64 - 1) / (WGW * 64));
     const size_t lds = step_dyn_lds<MULTI>(a);
+    // (launched by name, not through a function-pointer variable: a host build with -fsanitize=address was seen to push the call
+    // configuration and then NOT launch through the pointer -- no error, no kernel; the pointer only serves the occupancy query)
     if (act_f64) {
-        auto k = stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, double, false, WGW>;
-        hipLaunchKernelGGL(k, grid, dim3(WGW * 64), lds, st, with_snake_rule(a, k, WGW, lds, nwg));
+        const StepArgs b = with_snake_rule(a, (const void*)&stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, double, false, WGW>, WGW, lds, nwg);
+        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, double, false, WGW>), grid, dim3(WGW * 64), lds, st, b);
     } else {
-        auto k = stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, float, false, WGW>;
-        hipLaunchKernelGGL(k, grid, dim3(WGW * 64), lds, st, with_snake_rule(a, k, WGW, lds, nwg));
+        const StepArgs b = with_snake_rule(a, (const void*)&stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, float, false, WGW>, WGW, lds, nwg);
+        hipLaunchKernelGGL((stg_step_kernel<SOLVER, THERMAL, MULTI, AXIS_Z, DEVPHYS, float, false, WGW>), grid, dim3(WGW * 64), lds, st, b);
     }
 }
 
