@@ -36,3 +36,16 @@ def test_a_wrong_world_size_is_reported():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--pmc", "off"], cwd=ROOT,
                        env=dict(CLEAN, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_traffic_from_counters_prices_scattered_and_coalesced_reads():
+    """bench.py's HBM traffic from FETCH_SIZE / WRITE_SIZE (KB): gfx950 counts a coalesced stream's reads at half and scattered 64-byte
+    records exactly (profiles/r04_hbm_scatter_calibration.txt), so only the coalesced share is doubled."""
+    sys.path.insert(0, ROOT)
+    import bench
+    c = {"FETCH_SIZE": 1000.0, "WRITE_SIZE": 3000.0}
+    assert bench.traffic_bytes(None) is None and bench.traffic_bytes({"FETCH_SIZE": 1.0}) is None
+    assert bench.traffic_bytes(c) == (2 * 1000 + 3000) * 1024                        # every read a coalesced stream
+    assert bench.traffic_bytes(c, 0) == (1000 + 3000) * 1024                         # every read a scattered record
+    assert bench.traffic_bytes(c, 200 * 1024) == (1000 + 100 + 3000) * 1024          # + half the coalesced streams' bytes
+    assert bench.traffic_bytes(c, 10 ** 12) == bench.traffic_bytes(c)                # never more than all reads doubled
